@@ -1,0 +1,36 @@
+// common.h -- shared host/device helpers of libepnet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "epnet_ops.h"
+
+namespace epnet {
+
+constexpr int kWave = 64;  // CDNA4 wavefront
+
+// Records the HIP error text for epnet_last_hip_error() and maps it to EPNET_ELAUNCH.
+int record_hip_error(hipError_t e, const char *where);
+
+inline int check_launch(const char *where) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return record_hip_error(e, where);
+    return EPNET_OK;
+}
+
+inline int div_up(int a, int b) { return (a + b - 1) / b; }
+inline long long div_up64(long long a, long long b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+
+// number of set bits of `mask` strictly below this lane
+__device__ __forceinline__ int popc_below(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+}
+
+}  // namespace epnet
+
+#define EPNET_REQUIRE(cond) \
+    do {                    \
+        if (!(cond)) return EPNET_EINVAL; \
+    } while (0)

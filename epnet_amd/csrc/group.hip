@@ -1,0 +1,164 @@
+// group.hip -- index gathers (gather_points, group_points) and their scatter-add gradients.
+//
+// Replaces gather_points{,_grad}_kernel_fast (pointnet2_lib/pointnet2/src/sampling_gpu.cu:8-83) and
+// group_points{,_grad}_kernel_fast (group_points_gpu.cu:8-86). Both forward ops are the same 1-D
+// gather per channel row: out[b,c,q] = points[b,c,idx[b,q]], q over M (gather) or M*nsample
+// (group). These are the HBM-bound kernels of the SA stack (95 % of its compulsory bytes):
+//
+//   forward : a thread owns 4 consecutive output positions, loads their 4 indices ONCE (16-B
+//             load) and reuses them for a chunk of channels -- the reference re-reads idx for
+//             every channel (grid.y = C) -- and writes 16-B coalesced stores; the random 4-B
+//             reads hit a channel row of N*4 B that stays in L1/L2.
+//   backward: the reference issues one global atomicAdd per element. Here a workgroup owns
+//             (scene, a few channel rows), accumulates the row in LDS with ds_add_f32 and adds it
+//             to grad_points with plain coalesced stores: no global atomics, no cross-workgroup
+//             races. Summation order within a row is still unspecified (as it is in the
+//             reference), so gradients are compared to 1e-5, not bit-for-bit.
+#include "common.h"
+
+namespace epnet {
+
+constexpr int kGThreads = 256;
+constexpr int kGChan = 16;  // channels per workgroup in the forward gather
+
+// vectorised: p % 4 == 0 (so every row of idx/out is 16-B aligned given 16-B aligned bases)
+__global__ __launch_bounds__(kGThreads) void gather_rows_vec4_kernel(int c, int n, int p,
+                                                                     const float *__restrict__ points,
+                                                                     const int *__restrict__ idx,
+                                                                     float *__restrict__ out) {
+    const int bs = blockIdx.z;
+    const int c0 = blockIdx.y * kGChan;
+    const int q4 = blockIdx.x * kGThreads + threadIdx.x;  // group of 4 positions
+    if (q4 * 4 >= p) return;
+    const int4 id = *reinterpret_cast<const int4 *>(idx + (size_t)bs * p + (size_t)q4 * 4);
+    const int cend = min(c, c0 + kGChan);
+    const float *src = points + ((size_t)bs * c + c0) * n;
+    float *dst = out + ((size_t)bs * c + c0) * p + (size_t)q4 * 4;
+#pragma unroll 4
+    for (int ci = c0; ci < cend; ++ci) {
+        float4 v;
+        v.x = src[id.x];
+        v.y = src[id.y];
+        v.z = src[id.z];
+        v.w = src[id.w];
+        *reinterpret_cast<float4 *>(dst) = v;
+        src += n;
+        dst += p;
+    }
+}
+
+__global__ __launch_bounds__(kGThreads) void gather_rows_scalar_kernel(int c, int n, int p,
+                                                                       const float *__restrict__ points,
+                                                                       const int *__restrict__ idx,
+                                                                       float *__restrict__ out) {
+    const int bs = blockIdx.z;
+    const int c0 = blockIdx.y * kGChan;
+    const int q = blockIdx.x * kGThreads + threadIdx.x;
+    if (q >= p) return;
+    const int id = idx[(size_t)bs * p + q];
+    const int cend = min(c, c0 + kGChan);
+    for (int ci = c0; ci < cend; ++ci)
+        out[((size_t)bs * c + ci) * p + q] = points[((size_t)bs * c + ci) * n + id];
+}
+
+// scatter-add with the destination rows held in LDS. dynamic LDS: rows * n floats.
+__global__ __launch_bounds__(kGThreads) void scatter_rows_lds_kernel(int c, int n, int p, int rows,
+                                                                     const float *__restrict__ grad_out,
+                                                                     const int *__restrict__ idx,
+                                                                     float *__restrict__ grad_points) {
+    extern __shared__ float acc[];
+    const int bs = blockIdx.y;
+    const int c0 = blockIdx.x * rows;
+    const int nr = min(rows, c - c0);
+    for (int e = threadIdx.x; e < nr * n; e += kGThreads) acc[e] = 0.f;
+    __syncthreads();
+    const int *ix = idx + (size_t)bs * p;
+    const float *go = grad_out + ((size_t)bs * c + c0) * p;
+    for (int q = threadIdx.x; q < p; q += kGThreads) {
+        const int id = ix[q];
+        for (int r = 0; r < nr; ++r) atomicAdd(&acc[r * n + id], go[(size_t)r * p + q]);
+    }
+    __syncthreads();
+    float *gp = grad_points + ((size_t)bs * c + c0) * n;
+    for (int e = threadIdx.x; e < nr * n; e += kGThreads) gp[e] += acc[e];
+}
+
+// fallback for rows that do not fit LDS: global float atomics, as the reference does
+__global__ __launch_bounds__(kGThreads) void scatter_rows_atomic_kernel(int c, int n, int p,
+                                                                        const float *__restrict__ grad_out,
+                                                                        const int *__restrict__ idx,
+                                                                        float *__restrict__ grad_points) {
+    const int bs = blockIdx.z, ci = blockIdx.y;
+    const int q = blockIdx.x * kGThreads + threadIdx.x;
+    if (q >= p) return;
+    atomicAdd(grad_points + ((size_t)bs * c + ci) * n + idx[(size_t)bs * p + q],
+              grad_out[((size_t)bs * c + ci) * p + q]);
+}
+
+static int launch_gather_rows(int b, int c, int n, long long p, const float *points, const int *idx, float *out,
+                              hipStream_t s, const char *what) {
+    if (b == 0 || c == 0 || p == 0) return EPNET_OK;
+    if (!(points && idx && out)) return EPNET_EINVAL;
+    if (p > 0x7fffffffll || b > 65535 || div_up(c, kGChan) > 65535) return EPNET_ELIMIT;
+    const bool vec = (p % 4 == 0) && (((uintptr_t)idx | (uintptr_t)out) % 16 == 0);
+    if (vec) {
+        dim3 grid((unsigned)div_up64(p / 4, kGThreads), div_up(c, kGChan), b);
+        hipLaunchKernelGGL(gather_rows_vec4_kernel, grid, dim3(kGThreads), 0, s, c, n, (int)p, points, idx, out);
+    } else {
+        dim3 grid((unsigned)div_up64(p, kGThreads), div_up(c, kGChan), b);
+        hipLaunchKernelGGL(gather_rows_scalar_kernel, grid, dim3(kGThreads), 0, s, c, n, (int)p, points, idx, out);
+    }
+    return check_launch(what);
+}
+
+static int launch_scatter_rows(int b, int c, int n, long long p, const float *grad_out, const int *idx,
+                               float *grad_points, hipStream_t s, const char *what) {
+    if (b == 0 || c == 0 || p == 0 || n == 0) return EPNET_OK;
+    if (!(grad_out && idx && grad_points)) return EPNET_EINVAL;
+    if (p > 0x7fffffffll || b > 65535) return EPNET_ELIMIT;
+    constexpr int kLdsBudget = 64 * 1024;  // two workgroups per CU
+    if ((size_t)n * 4 <= kLdsBudget) {
+        int rows = kLdsBudget / (n * 4);
+        if (rows > 8) rows = 8;
+        if (rows > c) rows = c;
+        dim3 grid(div_up(c, rows), b);
+        hipLaunchKernelGGL(scatter_rows_lds_kernel, grid, dim3(kGThreads), (size_t)rows * n * 4, s, c, n, (int)p, rows,
+                           grad_out, idx, grad_points);
+    } else {
+        if (c > 65535) return EPNET_ELIMIT;
+        dim3 grid((unsigned)div_up64(p, kGThreads), c, b);
+        hipLaunchKernelGGL(scatter_rows_atomic_kernel, grid, dim3(kGThreads), 0, s, c, n, (int)p, grad_out, idx,
+                           grad_points);
+    }
+    return check_launch(what);
+}
+
+}  // namespace epnet
+
+using namespace epnet;
+
+extern "C" int epnet_gather_points(int b, int c, int n, int npoints, const float *points, const int *idx, float *out,
+                                   epnet_stream_t stream) {
+    EPNET_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0);
+    return launch_gather_rows(b, c, n, npoints, points, idx, out, (hipStream_t)stream, "gather_points");
+}
+
+extern "C" int epnet_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out, const int *idx,
+                                        float *grad_points, epnet_stream_t stream) {
+    EPNET_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0);
+    return launch_scatter_rows(b, c, n, npoints, grad_out, idx, grad_points, (hipStream_t)stream, "gather_points_grad");
+}
+
+extern "C" int epnet_group_points(int b, int c, int n, int npoints, int nsample, const float *points, const int *idx,
+                                  float *out, epnet_stream_t stream) {
+    EPNET_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0 && nsample >= 0);
+    return launch_gather_rows(b, c, n, (long long)npoints * nsample, points, idx, out, (hipStream_t)stream,
+                              "group_points");
+}
+
+extern "C" int epnet_group_points_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out,
+                                       const int *idx, float *grad_points, epnet_stream_t stream) {
+    EPNET_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0 && nsample >= 0);
+    return launch_scatter_rows(b, c, n, (long long)npoints * nsample, grad_out, idx, grad_points, (hipStream_t)stream,
+                               "group_points_grad");
+}

@@ -1,0 +1,352 @@
+// iou3d.hip -- rotated-box BEV overlap / IoU and NMS (rotated and axis-aligned) for gfx950.
+//
+// Replaces lib/utils/iou3d/src/iou3d_kernel.cu (box_overlap :108-212, iou_bev :214-221,
+// boxes_overlap_kernel :223-234, boxes_iou_bev_kernel :236-248, nms_kernel :250-292, iou_normal
+// :295-303, nms_normal_kernel :306-348) and the host half of lib/utils/iou3d/src/iou3d.cpp:73-170.
+//
+// Differences in structure, not in results:
+//   * box_overlap evaluates each polygon vertex's atan2 once and bubble-sorts on the stored
+//     angles (the reference recomputes two atan2 per comparison, :104-106, :188-196): the same
+//     deterministic function of the same arguments, hence the same swaps in the same order;
+//   * the NMS bit-mask is computed for the upper triangle of 64x64 tiles only -- the host sweep
+//     (iou3d.cpp:111-114) never reads a word left of the diagonal;
+//   * the greedy sweep runs on the device (one workgroup): no cudaMalloc / 5 MB device->host
+//     copy / host loop per call (iou3d.cpp:87-116).
+// Trigonometry: correctly rounded float cos/sin/atan2 via the double-precision functions, the
+// same definition the oracle uses (DESIGN.md "Parity definition").
+#include <math.h>
+
+#include "common.h"
+
+namespace epnet {
+
+constexpr float kIouEps = 1e-8f;  // iou3d_kernel.cu:13
+
+__device__ __forceinline__ float cr_cosf(float x) { return (float)cos((double)x); }
+__device__ __forceinline__ float cr_sinf(float x) { return (float)sin((double)x); }
+__device__ __forceinline__ float cr_atan2f(float y, float x) { return (float)atan2((double)y, (double)x); }
+
+struct P2 {
+    float x, y;
+};
+
+__device__ __forceinline__ float cross3(P2 p1, P2 p2, P2 p0) {  // :38-40
+    return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y);
+}
+
+__device__ __forceinline__ bool rect_cross(P2 p1, P2 p2, P2 q1, P2 q2) {  // :42-48
+    return fminf(p1.x, p2.x) <= fmaxf(q1.x, q2.x) && fminf(q1.x, q2.x) <= fmaxf(p1.x, p2.x) &&
+           fminf(p1.y, p2.y) <= fmaxf(q1.y, q2.y) && fminf(q1.y, q2.y) <= fmaxf(p1.y, p2.y);
+}
+
+// check_in_box2d (:50-65) with the box's cos(-ry), sin(-ry) passed in
+__device__ __forceinline__ bool in_box2d(const float *box, float ncos, float nsin, P2 p) {
+    const float MARGIN = 1e-5f;
+    const float center_x = (box[0] + box[2]) / 2;
+    const float center_y = (box[1] + box[3]) / 2;
+    const float rot_x = (p.x - center_x) * ncos + (p.y - center_y) * nsin + center_x;
+    const float rot_y = -(p.x - center_x) * nsin + (p.y - center_y) * ncos + center_y;
+    return rot_x > box[0] - MARGIN && rot_x < box[2] + MARGIN && rot_y > box[1] - MARGIN && rot_y < box[3] + MARGIN;
+}
+
+__device__ __forceinline__ bool seg_intersection(P2 p1, P2 p0, P2 q1, P2 q0, P2 &ans) {  // :67-96
+    if (!rect_cross(p0, p1, q0, q1)) return false;
+    const float s1 = cross3(q0, p1, p0);
+    const float s2 = cross3(p1, q1, p0);
+    const float s3 = cross3(p0, q1, q0);
+    const float s4 = cross3(q1, p1, q0);
+    if (!(s1 * s2 > 0 && s3 * s4 > 0)) return false;
+    const float s5 = cross3(q1, p1, p0);
+    if (fabsf(s5 - s1) > kIouEps) {
+        ans.x = (s5 * q0.x - s1 * q1.x) / (s5 - s1);
+        ans.y = (s5 * q0.y - s1 * q1.y) / (s5 - s1);
+    } else {
+        const float a0 = p0.y - p1.y, b0 = p1.x - p0.x, c0 = p0.x * p1.y - p1.x * p0.y;
+        const float a1 = q0.y - q1.y, b1 = q1.x - q0.x, c1 = q0.x * q1.y - q1.x * q0.y;
+        const float D = a0 * b1 - a1 * b0;
+        ans.x = (b0 * c1 - b1 * c0) / D;
+        ans.y = (a1 * c0 - a0 * c1) / D;
+    }
+    return true;
+}
+
+__device__ __forceinline__ void rot_center(P2 center, float c, float s, P2 &p) {  // :98-102
+    const float nx = (p.x - center.x) * c + (p.y - center.y) * s + center.x;
+    const float ny = -(p.x - center.x) * s + (p.y - center.y) * c + center.y;
+    p.x = nx;
+    p.y = ny;
+}
+
+// per-box trigonometry: cos/sin of +ry (corner rotation) and of -ry (point-in-box test)
+struct BoxTrig {
+    float c, s, nc, ns;
+};
+
+__device__ __forceinline__ BoxTrig box_trig(float ry) {
+    BoxTrig t;
+    t.c = cr_cosf(ry);
+    t.s = cr_sinf(ry);
+    t.nc = cr_cosf(-ry);
+    t.ns = cr_sinf(-ry);
+    return t;
+}
+
+__device__ float box_overlap(const float *box_a, const float *box_b, BoxTrig ta, BoxTrig tb) {  // :108-212
+    const float a_x1 = box_a[0], a_y1 = box_a[1], a_x2 = box_a[2], a_y2 = box_a[3];
+    const float b_x1 = box_b[0], b_y1 = box_b[1], b_x2 = box_b[2], b_y2 = box_b[3];
+    const P2 center_a = {(a_x1 + a_x2) / 2, (a_y1 + a_y2) / 2};
+    const P2 center_b = {(b_x1 + b_x2) / 2, (b_y1 + b_y2) / 2};
+    P2 ac[5] = {{a_x1, a_y1}, {a_x2, a_y1}, {a_x2, a_y2}, {a_x1, a_y2}, {0.f, 0.f}};
+    P2 bc[5] = {{b_x1, b_y1}, {b_x2, b_y1}, {b_x2, b_y2}, {b_x1, b_y2}, {0.f, 0.f}};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        rot_center(center_a, ta.c, ta.s, ac[k]);
+        rot_center(center_b, tb.c, tb.s, bc[k]);
+    }
+    ac[4] = ac[0];
+    bc[4] = bc[0];
+
+    P2 cp[24];  // the reference has 16 slots; two rectangles cannot produce more than 16 entries
+    float ang[24];
+    P2 pc = {0.f, 0.f};
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            P2 r;
+            if (seg_intersection(ac[i + 1], ac[i], bc[j + 1], bc[j], r)) {
+                pc.x = pc.x + r.x;
+                pc.y = pc.y + r.y;
+                cp[cnt++] = r;
+            }
+        }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (in_box2d(box_a, ta.nc, ta.ns, bc[k])) {
+            pc.x = pc.x + bc[k].x;
+            pc.y = pc.y + bc[k].y;
+            cp[cnt++] = bc[k];
+        }
+        if (in_box2d(box_b, tb.nc, tb.ns, ac[k])) {
+            pc.x = pc.x + ac[k].x;
+            pc.y = pc.y + ac[k].y;
+            cp[cnt++] = ac[k];
+        }
+    }
+    pc.x /= cnt;
+    pc.y /= cnt;
+
+    for (int i = 0; i < cnt; ++i) ang[i] = cr_atan2f(cp[i].y - pc.y, cp[i].x - pc.x);
+    for (int j = 0; j < cnt - 1; ++j)
+        for (int i = 0; i < cnt - j - 1; ++i)
+            if (ang[i] > ang[i + 1]) {
+                const P2 tp = cp[i];
+                cp[i] = cp[i + 1];
+                cp[i + 1] = tp;
+                const float ta_ = ang[i];
+                ang[i] = ang[i + 1];
+                ang[i + 1] = ta_;
+            }
+
+    float area = 0.f;
+    for (int k = 0; k < cnt - 1; ++k) {
+        const float ax = cp[k].x - cp[0].x, ay = cp[k].y - cp[0].y;
+        const float bx = cp[k + 1].x - cp[0].x, by = cp[k + 1].y - cp[0].y;
+        area += ax * by - ay * bx;
+    }
+    return fabsf(area) / 2.0f;
+}
+
+__device__ __forceinline__ float iou_bev(const float *box_a, const float *box_b, BoxTrig ta, BoxTrig tb) {  // :214-221
+    const float sa = (box_a[2] - box_a[0]) * (box_a[3] - box_a[1]);
+    const float sb = (box_b[2] - box_b[0]) * (box_b[3] - box_b[1]);
+    const float s_overlap = box_overlap(box_a, box_b, ta, tb);
+    return s_overlap / fmaxf(sa + sb - s_overlap, kIouEps);
+}
+
+__device__ __forceinline__ float iou_normal(const float *a, const float *b) {  // :295-303
+    const float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]);
+    const float top = fmaxf(a[1], b[1]), bottom = fminf(a[3], b[3]);
+    const float width = fmaxf(right - left, 0.f), height = fmaxf(bottom - top, 0.f);
+    const float interS = width * height;
+    const float Sa = (a[2] - a[0]) * (a[3] - a[1]);
+    const float Sb = (b[2] - b[0]) * (b[3] - b[1]);
+    return interS / fmaxf(Sa + Sb - interS, kIouEps);
+}
+
+// one thread per (a, b) pair; 64 b's x 4 a's per workgroup, the b boxes' trig staged in LDS
+template <bool IOU>
+__global__ __launch_bounds__(256) void pairwise_bev_kernel(int num_a, const float *__restrict__ boxes_a, int num_b,
+                                                           const float *__restrict__ boxes_b, float *__restrict__ ans) {
+    const int b_idx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int a_idx = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (a_idx >= num_a || b_idx >= num_b) return;
+    float ba[5], bb[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        ba[i] = boxes_a[a_idx * 5 + i];
+        bb[i] = boxes_b[b_idx * 5 + i];
+    }
+    const BoxTrig ta = box_trig(ba[4]), tb = box_trig(bb[4]);
+    ans[(size_t)a_idx * num_b + b_idx] = IOU ? iou_bev(ba, bb, ta, tb) : box_overlap(ba, bb, ta, tb);
+}
+
+// suppression bit-mask, upper triangle of 64x64 tiles: one wave per (row tile <= col tile)
+template <bool ROTATED>
+__global__ __launch_bounds__(64) void nms_mask_kernel(int boxes_num, float thresh, const float *__restrict__ boxes,
+                                                      unsigned long long *__restrict__ mask) {
+    const int row_start = blockIdx.y, col_start = blockIdx.x;
+    if (row_start > col_start) return;
+    const int row_size = min(boxes_num - row_start * 64, 64);
+    const int col_size = min(boxes_num - col_start * 64, 64);
+    __shared__ float block_boxes[64 * 5];
+    __shared__ BoxTrig block_trig[64];
+    const int t = threadIdx.x;
+    if (t < col_size) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) block_boxes[t * 5 + i] = boxes[(64 * col_start + t) * 5 + i];
+        if (ROTATED) block_trig[t] = box_trig(block_boxes[t * 5 + 4]);
+    }
+    __syncthreads();
+    if (t < row_size) {
+        const int cur = 64 * row_start + t;
+        float cb[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) cb[i] = boxes[cur * 5 + i];
+        BoxTrig ct = {0.f, 0.f, 0.f, 0.f};
+        if (ROTATED) ct = box_trig(cb[4]);
+        unsigned long long bits = 0;
+        const int start = (row_start == col_start) ? t + 1 : 0;
+        for (int i = start; i < col_size; ++i) {
+            const float v = ROTATED ? iou_bev(cb, block_boxes + i * 5, ct, block_trig[i])
+                                    : iou_normal(cb, block_boxes + i * 5);
+            if (v > thresh) bits |= 1ull << i;
+        }
+        const int col_blocks = (boxes_num + 63) / 64;
+        mask[(size_t)cur * col_blocks + col_start] = bits;
+    }
+}
+
+// Greedy sweep of iou3d.cpp:100-116 on the device, one workgroup. For each 64-box tile: wave 0
+// resolves the tile against its diagonal mask words (a 64-step scalar recurrence on readlane'd
+// words), appends the kept positions, then all threads OR the kept rows into the removed-set
+// words to the right of the tile.
+constexpr int kSweepThreads = 1024;
+__global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(int boxes_num,
+                                                                  const unsigned long long *__restrict__ mask,
+                                                                  long long *__restrict__ keep,
+                                                                  int *__restrict__ num_keep) {
+    extern __shared__ unsigned long long remv[];  // col_blocks words
+    __shared__ unsigned long long kept_bits;
+    __shared__ int kept_total;
+    const int col_blocks = (boxes_num + 63) / 64;
+    for (int j = threadIdx.x; j < col_blocks; j += kSweepThreads) remv[j] = 0ull;
+    if (threadIdx.x == 0) kept_total = 0;
+    __syncthreads();
+    for (int blk = 0; blk < col_blocks; ++blk) {
+        const int size = min(boxes_num - blk * 64, 64);
+        if (threadIdx.x < 64) {
+            const int lane = threadIdx.x;
+            unsigned long long diag = 0ull;
+            if (lane < size) diag = mask[(size_t)(blk * 64 + lane) * col_blocks + blk];
+            const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+            unsigned long long alive = ~remv[blk];
+            if (size < 64) alive &= (1ull << size) - 1ull;
+            unsigned long long kept = 0ull;
+            for (int i = 0; i < 64; ++i) {
+                if ((alive >> i) & 1ull) {  // wave-uniform
+                    kept |= 1ull << i;
+                    const unsigned long long row = ((unsigned long long)__builtin_amdgcn_readlane(dhi, i) << 32) |
+                                                   (unsigned long long)__builtin_amdgcn_readlane(dlo, i);
+                    alive &= ~row;
+                }
+            }
+            const int base = kept_total;
+            if ((kept >> lane) & 1ull) keep[base + __popcll(kept & ((1ull << lane) - 1ull))] = blk * 64 + lane;
+            if (lane == 0) {
+                kept_bits = kept;
+                kept_total = base + (int)__popcll(kept);
+            }
+        }
+        __syncthreads();
+        const unsigned long long kb = kept_bits;
+        for (int j = blk + 1 + threadIdx.x; j < col_blocks; j += kSweepThreads) {
+            unsigned long long acc = remv[j];
+            unsigned long long rest = kb;
+            while (rest) {
+                const int i = __builtin_ctzll(rest);
+                rest &= rest - 1ull;
+                acc |= mask[(size_t)(blk * 64 + i) * col_blocks + j];
+            }
+            remv[j] = acc;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *num_keep = kept_total;
+}
+
+template <bool ROTATED>
+static int nms_impl(const float *boxes, int boxes_num, float thresh, void *workspace, size_t workspace_bytes,
+                    int64_t *keep, int *num_keep, hipStream_t s) {
+    if (boxes_num < 0) return EPNET_EINVAL;
+    if (!num_keep) return EPNET_EINVAL;
+    if (boxes_num == 0) {
+        hipError_t e = hipMemsetAsync(num_keep, 0, sizeof(int), s);
+        return e == hipSuccess ? EPNET_OK : record_hip_error(e, "nms memset");
+    }
+    if (!(boxes && keep && workspace)) return EPNET_EINVAL;
+    if (workspace_bytes < epnet_nms_workspace_bytes(boxes_num)) return EPNET_ENOMEM;
+    const int col_blocks = (boxes_num + 63) / 64;
+    if (col_blocks > 65535 || (size_t)col_blocks * 8 > 60 * 1024) return EPNET_ELIMIT;
+    unsigned long long *mask = (unsigned long long *)workspace;
+    hipLaunchKernelGGL(nms_mask_kernel<ROTATED>, dim3(col_blocks, col_blocks), dim3(64), 0, s, boxes_num, thresh, boxes,
+                       mask);
+    int rc = check_launch("nms_mask");
+    if (rc) return rc;
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(kSweepThreads), (size_t)col_blocks * 8, s, boxes_num, mask,
+                       (long long *)keep, num_keep);
+    return check_launch("nms_sweep");
+}
+
+}  // namespace epnet
+
+using namespace epnet;
+
+extern "C" int epnet_boxes_overlap_bev(int num_a, const float *boxes_a, int num_b, const float *boxes_b, float *ans,
+                                       epnet_stream_t stream) {
+    EPNET_REQUIRE(num_a >= 0 && num_b >= 0);
+    if (num_a == 0 || num_b == 0) return EPNET_OK;
+    EPNET_REQUIRE(boxes_a && boxes_b && ans);
+    if (div_up(num_a, 4) > 65535) return EPNET_ELIMIT;
+    hipLaunchKernelGGL(pairwise_bev_kernel<false>, dim3(div_up(num_b, 64), div_up(num_a, 4)), dim3(256), 0,
+                       (hipStream_t)stream, num_a, boxes_a, num_b, boxes_b, ans);
+    return check_launch("boxes_overlap_bev");
+}
+
+extern "C" int epnet_boxes_iou_bev(int num_a, const float *boxes_a, int num_b, const float *boxes_b, float *ans,
+                                   epnet_stream_t stream) {
+    EPNET_REQUIRE(num_a >= 0 && num_b >= 0);
+    if (num_a == 0 || num_b == 0) return EPNET_OK;
+    EPNET_REQUIRE(boxes_a && boxes_b && ans);
+    if (div_up(num_a, 4) > 65535) return EPNET_ELIMIT;
+    hipLaunchKernelGGL(pairwise_bev_kernel<true>, dim3(div_up(num_b, 64), div_up(num_a, 4)), dim3(256), 0,
+                       (hipStream_t)stream, num_a, boxes_a, num_b, boxes_b, ans);
+    return check_launch("boxes_iou_bev");
+}
+
+extern "C" size_t epnet_nms_workspace_bytes(int boxes_num) {
+    if (boxes_num <= 0) return 0;
+    const size_t col_blocks = ((size_t)boxes_num + 63) / 64;
+    return (size_t)boxes_num * col_blocks * sizeof(unsigned long long);
+}
+
+extern "C" int epnet_nms(const float *boxes, int boxes_num, float thresh, void *workspace, size_t workspace_bytes,
+                         int64_t *keep, int *num_keep, epnet_stream_t stream) {
+    return nms_impl<true>(boxes, boxes_num, thresh, workspace, workspace_bytes, keep, num_keep, (hipStream_t)stream);
+}
+
+extern "C" int epnet_nms_normal(const float *boxes, int boxes_num, float thresh, void *workspace,
+                                size_t workspace_bytes, int64_t *keep, int *num_keep, epnet_stream_t stream) {
+    return nms_impl<false>(boxes, boxes_num, thresh, workspace, workspace_bytes, keep, num_keep, (hipStream_t)stream);
+}

@@ -1,0 +1,97 @@
+"""Stand-in for the reference's ``pointnet2_cuda`` extension module.
+
+Same nine function names, positional argument orders and pre-allocated-output convention as
+pointnet2_lib/pointnet2/src/pointnet2_api.cpp:10-24 (note the quirks kept on purpose: ball_query
+takes new_xyz before xyz; three_interpolate is (b,c,m,n) but its grad is (b,c,n,m)). Each call
+validates its tensors, then hands raw device pointers and the tensor's current HIP stream to the C
+ABI in libepnet_hip.so. Failures raise RuntimeError; the reference prints and exit()s.
+"""
+import torch
+
+from . import _lib
+from ._tensor import dev_ptr, need, on_device_of
+
+_F, _I = torch.float32, torch.int32
+
+
+def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
+    """ball_query_wrapper_fast, pointnet2_lib/pointnet2/src/ball_query.cpp:14-25"""
+    pn, px, pi = dev_ptr(new_xyz, "new_xyz", _F), dev_ptr(xyz, "xyz", _F), dev_ptr(idx, "idx", _I)
+    need(new_xyz, b * m * 3, "new_xyz"); need(xyz, b * n * 3, "xyz"); need(idx, b * m * nsample, "idx")
+    with on_device_of(xyz) as s:
+        _lib.check(_lib.lib().epnet_ball_query(b, n, m, radius, nsample, pn, px, pi, s), "ball_query")
+    return 1
+
+
+def group_points_wrapper(b, c, n, npoints, nsample, points, idx, out):
+    """group_points_wrapper_fast, group_points.cpp:25-36"""
+    pp, pi, po = dev_ptr(points, "points", _F), dev_ptr(idx, "idx", _I), dev_ptr(out, "out", _F)
+    need(points, b * c * n, "points"); need(idx, b * npoints * nsample, "idx"); need(out, b * c * npoints * nsample, "out")
+    with on_device_of(points) as s:
+        _lib.check(_lib.lib().epnet_group_points(b, c, n, npoints, nsample, pp, pi, po, s), "group_points")
+    return 1
+
+
+def group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_points):
+    """group_points_grad_wrapper_fast, group_points.cpp:11-22"""
+    pg, pi, pp = dev_ptr(grad_out, "grad_out", _F), dev_ptr(idx, "idx", _I), dev_ptr(grad_points, "grad_points", _F)
+    need(grad_out, b * c * npoints * nsample, "grad_out"); need(idx, b * npoints * nsample, "idx")
+    need(grad_points, b * c * n, "grad_points")
+    with on_device_of(grad_out) as s:
+        _lib.check(_lib.lib().epnet_group_points_grad(b, c, n, npoints, nsample, pg, pi, pp, s), "group_points_grad")
+    return 1
+
+
+def gather_points_wrapper(b, c, n, npoints, points, idx, out):
+    """gather_points_wrapper_fast, sampling.cpp:11-20"""
+    pp, pi, po = dev_ptr(points, "points", _F), dev_ptr(idx, "idx", _I), dev_ptr(out, "out", _F)
+    need(points, b * c * n, "points"); need(idx, b * npoints, "idx"); need(out, b * c * npoints, "out")
+    with on_device_of(points) as s:
+        _lib.check(_lib.lib().epnet_gather_points(b, c, n, npoints, pp, pi, po, s), "gather_points")
+    return 1
+
+
+def gather_points_grad_wrapper(b, c, n, npoints, grad_out, idx, grad_points):
+    """gather_points_grad_wrapper_fast, sampling.cpp:23-33"""
+    pg, pi, pp = dev_ptr(grad_out, "grad_out", _F), dev_ptr(idx, "idx", _I), dev_ptr(grad_points, "grad_points", _F)
+    need(grad_out, b * c * npoints, "grad_out"); need(idx, b * npoints, "idx"); need(grad_points, b * c * n, "grad_points")
+    with on_device_of(grad_out) as s:
+        _lib.check(_lib.lib().epnet_gather_points_grad(b, c, n, npoints, pg, pi, pp, s), "gather_points_grad")
+    return 1
+
+
+def furthest_point_sampling_wrapper(b, n, m, points, temp, idx):
+    """furthest_point_sampling_wrapper, sampling.cpp:36-46"""
+    pp, pt, pi = dev_ptr(points, "points", _F), dev_ptr(temp, "temp", _F), dev_ptr(idx, "idx", _I)
+    need(points, b * n * 3, "points"); need(temp, b * n, "temp"); need(idx, b * m, "idx")
+    with on_device_of(points) as s:
+        _lib.check(_lib.lib().epnet_furthest_point_sampling(b, n, m, pp, pt, pi, s), "furthest_point_sampling")
+    return 1
+
+
+def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
+    """three_nn_wrapper_fast, interpolate.cpp:14-23"""
+    pu, pk = dev_ptr(unknown, "unknown", _F), dev_ptr(known, "known", _F)
+    pd, pi = dev_ptr(dist2, "dist2", _F), dev_ptr(idx, "idx", _I)
+    need(unknown, b * n * 3, "unknown"); need(known, b * m * 3, "known"); need(dist2, b * n * 3, "dist2"); need(idx, b * n * 3, "idx")
+    with on_device_of(unknown) as s:
+        _lib.check(_lib.lib().epnet_three_nn(b, n, m, pu, pk, pd, pi, s), "three_nn")
+
+
+def three_interpolate_wrapper(b, c, m, n, points, idx, weight, out):
+    """three_interpolate_wrapper_fast, interpolate.cpp:26-38"""
+    pp, pi = dev_ptr(points, "points", _F), dev_ptr(idx, "idx", _I)
+    pw, po = dev_ptr(weight, "weight", _F), dev_ptr(out, "out", _F)
+    need(points, b * c * m, "points"); need(idx, b * n * 3, "idx"); need(weight, b * n * 3, "weight"); need(out, b * c * n, "out")
+    with on_device_of(points) as s:
+        _lib.check(_lib.lib().epnet_three_interpolate(b, c, m, n, pp, pi, pw, po, s), "three_interpolate")
+
+
+def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_points):
+    """three_interpolate_grad_wrapper_fast, interpolate.cpp:41-54"""
+    pg, pi = dev_ptr(grad_out, "grad_out", _F), dev_ptr(idx, "idx", _I)
+    pw, pp = dev_ptr(weight, "weight", _F), dev_ptr(grad_points, "grad_points", _F)
+    need(grad_out, b * c * n, "grad_out"); need(idx, b * n * 3, "idx"); need(weight, b * n * 3, "weight")
+    need(grad_points, b * c * m, "grad_points")
+    with on_device_of(grad_out) as s:
+        _lib.check(_lib.lib().epnet_three_interpolate_grad(b, c, n, m, pg, pi, pw, pp, s), "three_interpolate_grad")

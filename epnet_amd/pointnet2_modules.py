@@ -1,0 +1,100 @@
+"""Set-abstraction (SA) and feature-propagation (FP) modules over the gfx950 operators.
+
+Same public classes, constructor keywords, return values and ``state_dict`` key names as the
+reference's pointnet2_lib/pointnet2/pointnet2_modules.py (``_PointnetSAModuleBase``:10,
+``PointnetSAModuleMSG``:75, ``PointnetSAModule``:112, ``PointnetFPModule``:133), so lib/net's
+``Pointnet2MSG`` / ``RCNNNet`` build on it unchanged and reference checkpoints load. The geometry
+ops (FPS, gather, ball query, grouping, three_nn, three_interpolate) run on the HIP kernels; the
+shared MLPs and the pooling stay on stock PyTorch-ROCm.
+"""
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import pointnet2_utils
+from . import pytorch_utils as pt_utils
+
+
+class _PointnetSAModuleBase(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.npoint = None
+        self.groupers = None
+        self.mlps = None
+        self.pool_method = 'max_pool'
+
+    def _pool(self, x: torch.Tensor) -> torch.Tensor:
+        window = [1, x.size(3)]
+        if self.pool_method == 'max_pool':
+            return F.max_pool2d(x, kernel_size=window)
+        if self.pool_method == 'avg_pool':
+            return F.avg_pool2d(x, kernel_size=window)
+        raise NotImplementedError
+
+    def forward(self, xyz: torch.Tensor, features: Optional[torch.Tensor] = None, new_xyz=None):
+        """xyz (B,N,3), features (B,C,N) -> (new_xyz (B,npoint,3), new_features (B,sum mlp[-1],npoint),
+        idx (B,npoint) int32 FPS indices or None). The 3-tuple (reference :72) is what
+        lib/net/pointnet2_msg.py:214-218 unpacks; LI-Fusion consumes idx."""
+        idx = None
+        if new_xyz is None and self.npoint is not None:
+            idx = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
+            channels_first = xyz.transpose(1, 2).contiguous()
+            new_xyz = pointnet2_utils.gather_operation(channels_first, idx).transpose(1, 2).contiguous()
+
+        pooled = []
+        for grouper, mlp in zip(self.groupers, self.mlps):
+            grouped = grouper(xyz, new_xyz, features)          # (B, 3+C, npoint, nsample)
+            pooled.append(self._pool(mlp(grouped)).squeeze(-1))  # (B, mlp[-1], npoint)
+        return new_xyz, torch.cat(pooled, dim=1), idx
+
+
+class PointnetSAModuleMSG(_PointnetSAModuleBase):
+    """multi-scale grouping SA layer"""
+
+    def __init__(self, *, npoint: int, radii: List[float], nsamples: List[int], mlps: List[List[int]],
+                 bn: bool = True, use_xyz: bool = True, pool_method='max_pool', instance_norm=False):
+        super().__init__()
+        assert len(radii) == len(nsamples) == len(mlps)
+        self.npoint = npoint
+        self.pool_method = pool_method
+        self.groupers = nn.ModuleList()
+        self.mlps = nn.ModuleList()
+        for radius, nsample, spec in zip(radii, nsamples, mlps):
+            self.groupers.append(pointnet2_utils.QueryAndGroup(radius, nsample, use_xyz=use_xyz)
+                                 if npoint is not None else pointnet2_utils.GroupAll(use_xyz))
+            if use_xyz:
+                spec[0] += 3  # in place, like the reference (:105-106): callers may rely on the mutated spec
+            self.mlps.append(pt_utils.SharedMLP(spec, bn=bn, instance_norm=instance_norm))
+
+
+class PointnetSAModule(PointnetSAModuleMSG):
+    """single-scale SA layer (npoint=None -> GroupAll)"""
+
+    def __init__(self, *, mlp: List[int], npoint: int = None, radius: float = None, nsample: int = None,
+                 bn: bool = True, use_xyz: bool = True, pool_method='max_pool', instance_norm=False):
+        super().__init__(mlps=[mlp], npoint=npoint, radii=[radius], nsamples=[nsample], bn=bn, use_xyz=use_xyz,
+                         pool_method=pool_method, instance_norm=instance_norm)
+
+
+class PointnetFPModule(nn.Module):
+    """propagates features of the `known` set onto the `unknown` set (inverse-distance weights
+    over the 3 nearest neighbours), then a shared MLP"""
+
+    def __init__(self, *, mlp: List[int], bn: bool = True, activation=nn.ReLU(inplace=True)):
+        super().__init__()
+        self.mlp = pt_utils.SharedMLP(mlp, bn=bn, activation=activation)
+
+    def forward(self, unknown: torch.Tensor, known: torch.Tensor, unknow_feats: torch.Tensor,
+                known_feats: torch.Tensor) -> torch.Tensor:
+        """unknown (B,n,3), known (B,m,3), unknow_feats (B,C1,n), known_feats (B,C2,m) -> (B,mlp[-1],n)"""
+        if known is None:
+            spread = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
+        else:
+            dist, idx = pointnet2_utils.three_nn(unknown, known)
+            inv = 1.0 / (dist + 1e-8)                               # reference :157-159
+            weight = inv / torch.sum(inv, dim=2, keepdim=True)
+            spread = pointnet2_utils.three_interpolate(known_feats, idx, weight)
+        feats = spread if unknow_feats is None else torch.cat([spread, unknow_feats], dim=1)
+        return self.mlp(feats.unsqueeze(-1)).squeeze(-1)

@@ -1,0 +1,202 @@
+"""PointNet++ operator surface backed by the gfx950 kernels.
+
+Re-provides the public names of the reference's pointnet2_lib/pointnet2/pointnet2_utils.py
+(``furthest_point_sample``:36, ``gather_operation``:73, ``three_nn``:105, ``three_interpolate``:153,
+``grouping_operation``:197, ``ball_query``:228, ``QueryAndGroup``:231, ``GroupAll``:267) with the
+same call signatures, dtypes and output shapes. Differences from the reference are limited to
+plumbing: outputs are allocated on the INPUT's device (the reference uses
+``torch.cuda.FloatTensor(...)``, i.e. whatever device is current), and errors raise instead of
+killing the process.
+"""
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from . import pointnet2_cuda as _ext
+
+
+def _new(like: torch.Tensor, shape, dtype=torch.float32, zero: bool = False) -> torch.Tensor:
+    alloc = torch.zeros if zero else torch.empty
+    return alloc(tuple(shape), dtype=dtype, device=like.device)
+
+
+class FurthestPointSampling(Function):
+    """(B,N,3) xyz -> (B,npoint) int32 indices; index 0 is always selected first.
+    reference: pointnet2_utils.py:10-33"""
+
+    @staticmethod
+    def forward(ctx, xyz: torch.Tensor, npoint: int) -> torch.Tensor:
+        assert xyz.is_contiguous()
+        batch, n = xyz.shape[0], xyz.shape[1]
+        out = _new(xyz, (batch, npoint), torch.int32)
+        running_min = torch.full((batch, n), 1e10, dtype=torch.float32, device=xyz.device)
+        _ext.furthest_point_sampling_wrapper(batch, n, npoint, xyz, running_min, out)
+        ctx.mark_non_differentiable(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad=None):
+        return None, None
+
+
+furthest_point_sample = FurthestPointSampling.apply
+
+
+class GatherOperation(Function):
+    """features (B,C,N), idx (B,npoint) int32 -> (B,C,npoint). reference: pointnet2_utils.py:39-70"""
+
+    @staticmethod
+    def forward(ctx, features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+        assert features.is_contiguous() and idx.is_contiguous()
+        batch, npoint = idx.shape
+        channels, n = features.shape[1], features.shape[2]
+        out = _new(features, (batch, channels, npoint))
+        _ext.gather_points_wrapper(batch, channels, n, npoint, features, idx, out)
+        ctx.for_backwards = (idx, channels, n)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, channels, n = ctx.for_backwards
+        batch, npoint = idx.shape
+        grad_features = _new(grad_out, (batch, channels, n), zero=True)
+        _ext.gather_points_grad_wrapper(batch, channels, n, npoint, grad_out.detach().contiguous(), idx, grad_features)
+        return grad_features, None
+
+
+gather_operation = GatherOperation.apply
+
+
+class ThreeNN(Function):
+    """unknown (B,n,3), known (B,m,3) -> (dist (B,n,3) L2 distances, idx (B,n,3) int32).
+    reference: pointnet2_utils.py:76-102 (the extension returns squared distances; sqrt here)"""
+
+    @staticmethod
+    def forward(ctx, unknown: torch.Tensor, known: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        assert unknown.is_contiguous() and known.is_contiguous()
+        batch, n = unknown.shape[0], unknown.shape[1]
+        m = known.shape[1]
+        dist2 = _new(unknown, (batch, n, 3))
+        idx = _new(unknown, (batch, n, 3), torch.int32)
+        _ext.three_nn_wrapper(batch, n, m, unknown, known, dist2, idx)
+        ctx.mark_non_differentiable(idx)
+        return torch.sqrt(dist2), idx
+
+    @staticmethod
+    def backward(ctx, a=None, b=None):
+        return None, None
+
+
+three_nn = ThreeNN.apply
+
+
+class ThreeInterpolate(Function):
+    """features (B,C,m), idx/weight (B,n,3) -> (B,C,n). reference: pointnet2_utils.py:108-150"""
+
+    @staticmethod
+    def forward(ctx, features: torch.Tensor, idx: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+        assert features.is_contiguous() and idx.is_contiguous() and weight.is_contiguous()
+        batch, channels, m = features.shape
+        n = idx.shape[1]
+        ctx.three_interpolate_for_backward = (idx, weight, m)
+        out = _new(features, (batch, channels, n))
+        _ext.three_interpolate_wrapper(batch, channels, m, n, features, idx, weight, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out: torch.Tensor):
+        idx, weight, m = ctx.three_interpolate_for_backward
+        batch, channels, n = grad_out.shape
+        grad_features = _new(grad_out, (batch, channels, m), zero=True)
+        _ext.three_interpolate_grad_wrapper(batch, channels, n, m, grad_out.detach().contiguous(), idx, weight,
+                                            grad_features)
+        return grad_features, None, None
+
+
+three_interpolate = ThreeInterpolate.apply
+
+
+class GroupingOperation(Function):
+    """features (B,C,N), idx (B,npoint,nsample) int32 -> (B,C,npoint,nsample).
+    reference: pointnet2_utils.py:156-194"""
+
+    @staticmethod
+    def forward(ctx, features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+        assert features.is_contiguous() and idx.is_contiguous()
+        batch, npoint, nsample = idx.shape
+        channels, n = features.shape[1], features.shape[2]
+        out = _new(features, (batch, channels, npoint, nsample))
+        _ext.group_points_wrapper(batch, channels, n, npoint, nsample, features, idx, out)
+        ctx.for_backwards = (idx, n)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out: torch.Tensor):
+        idx, n = ctx.for_backwards
+        batch, channels, npoint, nsample = grad_out.shape
+        grad_features = _new(grad_out, (batch, channels, n), zero=True)
+        _ext.group_points_grad_wrapper(batch, channels, n, npoint, nsample, grad_out.detach().contiguous(), idx,
+                                       grad_features)
+        return grad_features, None
+
+
+grouping_operation = GroupingOperation.apply
+
+
+class BallQuery(Function):
+    """radius, nsample, xyz (B,N,3), new_xyz (B,npoint,3) -> idx (B,npoint,nsample) int32: the first
+    nsample points (index order) strictly inside the ball, padded with the first hit; zeros for an
+    empty ball. reference: pointnet2_utils.py:200-225"""
+
+    @staticmethod
+    def forward(ctx, radius: float, nsample: int, xyz: torch.Tensor, new_xyz: torch.Tensor) -> torch.Tensor:
+        assert new_xyz.is_contiguous() and xyz.is_contiguous()
+        batch, n = xyz.shape[0], xyz.shape[1]
+        npoint = new_xyz.shape[1]
+        idx = _new(xyz, (batch, npoint, nsample), torch.int32, zero=True)
+        _ext.ball_query_wrapper(batch, n, npoint, radius, nsample, new_xyz, xyz, idx)
+        ctx.mark_non_differentiable(idx)
+        return idx
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None, None, None
+
+
+ball_query = BallQuery.apply
+
+
+class QueryAndGroup(nn.Module):
+    """ball_query -> group xyz -> subtract the centre -> group features -> concat [xyz(3), features(C)].
+    reference: pointnet2_utils.py:231-264"""
+
+    def __init__(self, radius: float, nsample: int, use_xyz: bool = True):
+        super().__init__()
+        self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
+
+    def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: Optional[torch.Tensor] = None):
+        idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
+        local_xyz = grouping_operation(xyz.transpose(1, 2).contiguous(), idx)  # (B,3,npoint,nsample)
+        local_xyz -= new_xyz.transpose(1, 2).unsqueeze(-1)
+        if features is None:
+            assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
+            return local_xyz
+        grouped = grouping_operation(features, idx)
+        return torch.cat([local_xyz, grouped], dim=1) if self.use_xyz else grouped
+
+
+class GroupAll(nn.Module):
+    """one group holding every point: (B, 3+C, 1, N). reference: pointnet2_utils.py:267-290"""
+
+    def __init__(self, use_xyz: bool = True):
+        super().__init__()
+        self.use_xyz = use_xyz
+
+    def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: Optional[torch.Tensor] = None):
+        all_xyz = xyz.transpose(1, 2).unsqueeze(2)
+        if features is None:
+            return all_xyz
+        all_feat = features.unsqueeze(2)
+        return torch.cat([all_xyz, all_feat], dim=1) if self.use_xyz else all_feat

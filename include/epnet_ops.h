@@ -1,0 +1,159 @@
+/*
+ * epnet_ops.h -- C ABI of the MI355X (gfx950) point-cloud geometry library, libepnet_hip.so.
+ *
+ * Every entry point below replaces one launcher of the reference's three CUDA extensions
+ * (pointnet2_cuda, iou3d_cuda, roipool3d_cuda); the reference interface it stands in for is
+ * cited as path:line relative to the reference checkout. Conventions:
+ *
+ *   - plain pointers and sizes only; no torch / pybind types;
+ *   - every device pointer is a HIP device address of a contiguous fp32 / int32 / int64 array
+ *     laid out exactly as the reference lays it out (shapes in the comments);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all device entry
+ *     points are asynchronous on that stream, allocate nothing, keep no state between calls and
+ *     are re-entrant (the reference's ops are called concurrently from several host threads
+ *     under nn.DataParallel, tools/train_rcnn.py:221-223);
+ *   - return value: EPNET_OK (0) or a negative EPNET_E* code; the library never calls exit()
+ *     (the reference does: e.g. pointnet2_lib/pointnet2/src/ball_query_gpu.cu:62-65);
+ *   - scratch memory is supplied by the caller (`*_workspace_bytes` + `workspace`), replacing
+ *     the per-call cudaMalloc/cudaFree of lib/utils/iou3d/src/iou3d.cpp:87,98 and
+ *     lib/utils/roipool3d/src/roipool3d_kernel.cu:214,222,231-232.
+ *
+ * Arithmetic contract (DESIGN.md "Parity definition"): IEEE fp32, source order, no fused
+ * contraction; integer outputs bit-exact versus oracle/ (the CPU restatement of the reference
+ * kernels), float copies exact, float sums to 1e-5.
+ */
+#ifndef EPNET_OPS_H
+#define EPNET_OPS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EPNET_ABI_VERSION 1
+
+#define EPNET_OK 0
+#define EPNET_EINVAL (-1)   /* bad size / NULL pointer */
+#define EPNET_ELAUNCH (-2)  /* hipLaunch / hipGetLastError reported a failure */
+#define EPNET_ENOMEM (-3)   /* workspace too small */
+#define EPNET_ELIMIT (-4)   /* problem size outside what the kernels support */
+
+typedef void *epnet_stream_t;
+
+int epnet_abi_version(void);
+const char *epnet_strerror(int code);
+/* last HIP error string recorded by this thread's most recent failing call ("" if none) */
+const char *epnet_last_hip_error(void);
+
+/* ----------------------------------------------------------------------------------------
+ * pointnet2 (pointnet2_lib/pointnet2/src/pointnet2_api.cpp:10-24)
+ * -------------------------------------------------------------------------------------- */
+
+/* furthest_point_sampling_kernel_launcher, sampling_gpu.cu:211-253 (wrapper sampling.cpp:36-46).
+ * xyz (B,N,3) f32; temp (B,N) f32 in/out running min squared distance, caller-filled with 1e10
+ * (pointnet2_utils.py:26); idx (B,M) i32 out. idx[:,0] = 0. Tie-breaks reproduce the reference
+ * block reduction for block size opt_n_threads(N) (cuda_utils.h:10-14). temp may be NULL: the
+ * kernel then starts from 1e10 and does not write the distances back. */
+int epnet_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp, int *idx,
+                                  epnet_stream_t stream);
+
+/* gather_points_kernel_launcher_fast, sampling_gpu.cu:26-43. points (B,C,N), idx (B,M) -> out (B,C,M) */
+int epnet_gather_points(int b, int c, int n, int npoints, const float *points, const int *idx,
+                        float *out, epnet_stream_t stream);
+
+/* gather_points_grad_kernel_launcher_fast, sampling_gpu.cu:65-83.
+ * grad_out (B,C,M), idx (B,M) -> grad_points (B,C,N) accumulated into (caller-zeroed, pointnet2_utils.py:67) */
+int epnet_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out, const int *idx,
+                             float *grad_points, epnet_stream_t stream);
+
+/* ball_query_kernel_launcher_fast, ball_query_gpu.cu:48-66 (note: new_xyz before xyz, ball_query.cpp:14).
+ * new_xyz (B,M,3), xyz (B,N,3) -> idx (B,M,nsample) i32. Every slot is written (zeros when the
+ * ball is empty; the reference leaves the caller's zero fill, pointnet2_utils.py:218). */
+int epnet_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                     const float *xyz, int *idx, epnet_stream_t stream);
+
+/* group_points_kernel_launcher_fast, group_points_gpu.cu:69-86.
+ * points (B,C,N), idx (B,M,ns) -> out (B,C,M,ns) */
+int epnet_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
+                       const int *idx, float *out, epnet_stream_t stream);
+
+/* group_points_grad_kernel_launcher_fast, group_points_gpu.cu:27-44.
+ * grad_out (B,C,M,ns), idx (B,M,ns) -> grad_points (B,C,N) accumulated into (caller-zeroed) */
+int epnet_group_points_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out,
+                            const int *idx, float *grad_points, epnet_stream_t stream);
+
+/* three_nn_kernel_launcher_fast, interpolate_gpu.cu:55-74.
+ * unknown (B,n,3), known (B,m,3) -> dist2 (B,n,3) f32 squared distances, idx (B,n,3) i32 */
+int epnet_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2,
+                   int *idx, epnet_stream_t stream);
+
+/* three_interpolate_kernel_launcher_fast, interpolate_gpu.cu:99-117 (argument order b,c,m,n).
+ * points (B,C,m), idx (B,n,3), weight (B,n,3) -> out (B,C,n) */
+int epnet_three_interpolate(int b, int c, int m, int n, const float *points, const int *idx,
+                            const float *weight, float *out, epnet_stream_t stream);
+
+/* three_interpolate_grad_kernel_launcher_fast, interpolate_gpu.cu:144-161 (argument order b,c,n,m).
+ * grad_out (B,C,n), idx, weight (B,n,3) -> grad_points (B,C,m) accumulated into (caller-zeroed) */
+int epnet_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out, const int *idx,
+                                 const float *weight, float *grad_points, epnet_stream_t stream);
+
+/* ----------------------------------------------------------------------------------------
+ * iou3d (lib/utils/iou3d/src/iou3d.cpp:174-179); boxes are (N,5) [x1,y1,x2,y2,ry] f32
+ * -------------------------------------------------------------------------------------- */
+
+/* boxesoverlapLauncher, iou3d_kernel.cu:354-363: ans (num_a,num_b) rotated-rectangle overlap area */
+int epnet_boxes_overlap_bev(int num_a, const float *boxes_a, int num_b, const float *boxes_b,
+                            float *ans_overlap, epnet_stream_t stream);
+
+/* boxesioubevLauncher, iou3d_kernel.cu:365-372: ans (num_a,num_b) rotated BEV IoU */
+int epnet_boxes_iou_bev(int num_a, const float *boxes_a, int num_b, const float *boxes_b,
+                        float *ans_iou, epnet_stream_t stream);
+
+/* bytes of device scratch epnet_nms / epnet_nms_normal need for `boxes_num` boxes */
+size_t epnet_nms_workspace_bytes(int boxes_num);
+
+/* nms_gpu, iou3d.cpp:73-120 (nmsLauncher iou3d_kernel.cu:374-379 + the host sweep :100-116).
+ * boxes (N,5) sorted by descending score. The suppression bit-mask and the greedy sweep both
+ * run on the device: keep (N) i64 device array receives the kept positions in increasing order,
+ * *num_keep (device i32) their count. The caller copies those back if it wants the reference's
+ * host-side `keep` (the Python shim does). */
+int epnet_nms(const float *boxes, int boxes_num, float nms_overlap_thresh, void *workspace,
+              size_t workspace_bytes, int64_t *keep, int *num_keep, epnet_stream_t stream);
+
+/* nms_normal_gpu, iou3d.cpp:123-170 (axis-aligned IoU of the [x1,y1,x2,y2] part, iou3d_kernel.cu:295-303) */
+int epnet_nms_normal(const float *boxes, int boxes_num, float nms_overlap_thresh, void *workspace,
+                     size_t workspace_bytes, int64_t *keep, int *num_keep, epnet_stream_t stream);
+
+/* ----------------------------------------------------------------------------------------
+ * roipool3d (lib/utils/roipool3d/src/roipool3d.cpp:198-203); boxes3d are (.,7) [x,y,z,h,w,l,ry]
+ * -------------------------------------------------------------------------------------- */
+
+size_t epnet_roipool3d_workspace_bytes(int batch_size, int boxes_num, int sampled_pts_num);
+
+/* roipool3dLauncher, roipool3d_kernel.cu:209-237 (also serves forward_slow, :197-206: same result).
+ * xyz (B,N,3), boxes3d (B,M,7), pts_feature (B,N,C) -> pooled_features (B,M,S,3+C) f32,
+ * pooled_empty_flag (B,M) i32. Rows of empty boxes are left untouched and the flag of non-empty
+ * boxes is left untouched, as in the reference (caller zero-fills both, roipool3d_utils.py:21-23). */
+int epnet_roipool3d(int batch_size, int pts_num, int boxes_num, int feature_in_len,
+                    int sampled_pts_num, const float *xyz, const float *boxes3d,
+                    const float *pts_feature, float *pooled_features, int *pooled_empty_flag,
+                    void *workspace, size_t workspace_bytes, epnet_stream_t stream);
+
+/* Host-memory ops: these are CPU ops in the reference itself (called from DataLoader worker
+ * processes, lib/datasets/kitti_rcnn_dataset.py:672,767,811,1029,1157), not a fallback.
+ * pts_in_boxes3d_cpu, roipool3d.cpp:97-125: pts (N,3), boxes3d (M,7) -> pts_flag (M,N) i64 */
+int epnet_pts_in_boxes3d_host(int64_t *pts_flag, const float *pts, const float *boxes3d,
+                              int64_t boxes_num, int64_t pts_num);
+
+/* roipool3d_cpu, roipool3d.cpp:127-195: -> pooled_pts (M,S,3), pooled_features (M,S,C), flag (M) i64 */
+int epnet_roipool3d_host(const float *pts, const float *boxes3d, const float *pts_feature,
+                         float *pooled_pts, float *pooled_features, int64_t *pooled_empty_flag,
+                         int64_t boxes_num, int64_t pts_num, int64_t feature_len,
+                         int64_t sampled_pts_num);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EPNET_OPS_H */

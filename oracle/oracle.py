@@ -1,0 +1,197 @@
+"""TEST INFRASTRUCTURE -- numpy front-end of the CPU oracle (oracle/epnet_oracle.c).
+
+Only tests/, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+module. It restates the reference's device kernels on the CPU (citations in epnet_oracle.c); it
+is the checker, never the thing shipped or measured as the product.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libepnet_oracle.so")
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "epnet_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "libepnet_oracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = ctypes.CDLL(_SO)
+        _lib.oracle_box_overlap.restype = ctypes.c_float
+        _lib.oracle_iou_bev.restype = ctypes.c_float
+        _lib.oracle_iou_normal.restype = ctypes.c_float
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+_F = ctypes.c_float
+_L = ctypes.c_long
+
+
+def opt_n_threads(n):
+    return int(lib().oracle_opt_n_threads(int(n)))
+
+
+def furthest_point_sampling(xyz, npoint, return_temp=False):
+    xyz = _f32(xyz)
+    b, n, _ = xyz.shape
+    temp = np.full((b, n), 1e10, dtype=np.float32)
+    idx = np.zeros((b, npoint), dtype=np.int32)
+    lib().oracle_furthest_point_sampling(b, n, npoint, _p(xyz), _p(temp), _p(idx))
+    return (idx, temp) if return_temp else idx
+
+
+def gather_points(points, idx):
+    points, idx = _f32(points), _i32(idx)
+    b, c, n = points.shape
+    m = idx.shape[1]
+    out = np.empty((b, c, m), dtype=np.float32)
+    lib().oracle_gather_points(b, c, n, m, _p(points), _p(idx), _p(out))
+    return out
+
+
+def gather_points_grad(grad_out, idx, n):
+    grad_out, idx = _f32(grad_out), _i32(idx)
+    b, c, m = grad_out.shape
+    g = np.zeros((b, c, n), dtype=np.float32)
+    lib().oracle_gather_points_grad(b, c, n, m, _p(grad_out), _p(idx), _p(g))
+    return g
+
+
+def ball_query(radius, nsample, xyz, new_xyz):
+    xyz, new_xyz = _f32(xyz), _f32(new_xyz)
+    b, n, _ = xyz.shape
+    m = new_xyz.shape[1]
+    idx = np.zeros((b, m, nsample), dtype=np.int32)
+    lib().oracle_ball_query(b, n, m, _F(radius), nsample, _p(new_xyz), _p(xyz), _p(idx))
+    return idx
+
+
+def group_points(points, idx):
+    points, idx = _f32(points), _i32(idx)
+    b, c, n = points.shape
+    _, m, ns = idx.shape
+    out = np.empty((b, c, m, ns), dtype=np.float32)
+    lib().oracle_group_points(b, c, n, m, ns, _p(points), _p(idx), _p(out))
+    return out
+
+
+def group_points_grad(grad_out, idx, n):
+    grad_out, idx = _f32(grad_out), _i32(idx)
+    b, c, m, ns = grad_out.shape
+    g = np.zeros((b, c, n), dtype=np.float32)
+    lib().oracle_group_points_grad(b, c, n, m, ns, _p(grad_out), _p(idx), _p(g))
+    return g
+
+
+def three_nn(unknown, known):
+    """returns (dist2, idx): SQUARED distances, as the extension does (the Python surface sqrt's them)."""
+    unknown, known = _f32(unknown), _f32(known)
+    b, n, _ = unknown.shape
+    m = known.shape[1]
+    dist2 = np.empty((b, n, 3), dtype=np.float32)
+    idx = np.empty((b, n, 3), dtype=np.int32)
+    lib().oracle_three_nn(b, n, m, _p(unknown), _p(known), _p(dist2), _p(idx))
+    return dist2, idx
+
+
+def three_interpolate(points, idx, weight):
+    points, idx, weight = _f32(points), _i32(idx), _f32(weight)
+    b, c, m = points.shape
+    n = idx.shape[1]
+    out = np.empty((b, c, n), dtype=np.float32)
+    lib().oracle_three_interpolate(b, c, m, n, _p(points), _p(idx), _p(weight), _p(out))
+    return out
+
+
+def three_interpolate_grad(grad_out, idx, weight, m):
+    grad_out, idx, weight = _f32(grad_out), _i32(idx), _f32(weight)
+    b, c, n = grad_out.shape
+    g = np.zeros((b, c, m), dtype=np.float32)
+    lib().oracle_three_interpolate_grad(b, c, n, m, _p(grad_out), _p(idx), _p(weight), _p(g))
+    return g
+
+
+def boxes_overlap_bev(boxes_a, boxes_b):
+    boxes_a, boxes_b = _f32(boxes_a), _f32(boxes_b)
+    out = np.empty((boxes_a.shape[0], boxes_b.shape[0]), dtype=np.float32)
+    lib().oracle_boxes_overlap_bev(boxes_a.shape[0], _p(boxes_a), boxes_b.shape[0], _p(boxes_b), _p(out))
+    return out
+
+
+def boxes_iou_bev(boxes_a, boxes_b):
+    boxes_a, boxes_b = _f32(boxes_a), _f32(boxes_b)
+    out = np.empty((boxes_a.shape[0], boxes_b.shape[0]), dtype=np.float32)
+    lib().oracle_boxes_iou_bev(boxes_a.shape[0], _p(boxes_a), boxes_b.shape[0], _p(boxes_b), _p(out))
+    return out
+
+
+def nms_mask(boxes, thresh, rotated):
+    boxes = _f32(boxes)
+    n = boxes.shape[0]
+    mask = np.zeros((n, (n + 63) // 64), dtype=np.uint64)
+    lib().oracle_nms_mask(n, _F(thresh), _p(boxes), _p(mask), int(bool(rotated)))
+    return mask
+
+
+def nms(boxes, thresh, rotated):
+    """boxes already sorted by descending score; returns kept positions (int64), like the ext."""
+    boxes = _f32(boxes)
+    n = boxes.shape[0]
+    keep = np.zeros((max(n, 1),), dtype=np.int64)
+    k = lib().oracle_nms(n, _F(thresh), _p(boxes), _p(keep), int(bool(rotated)))
+    return keep[:k].copy()
+
+
+def roipool3d(xyz, boxes3d, pts_feature, sampled_pts_num):
+    xyz, boxes3d, pts_feature = _f32(xyz), _f32(boxes3d), _f32(pts_feature)
+    b, n, _ = xyz.shape
+    m = boxes3d.shape[1]
+    c = pts_feature.shape[2]
+    pooled = np.zeros((b, m, sampled_pts_num, 3 + c), dtype=np.float32)
+    flag = np.zeros((b, m), dtype=np.int32)
+    lib().oracle_roipool3d(b, n, m, c, sampled_pts_num, _p(xyz), _p(boxes3d), _p(pts_feature), _p(pooled), _p(flag))
+    return pooled, flag
+
+
+def pts_in_boxes3d(pts, boxes3d):
+    pts, boxes3d = _f32(pts), _f32(boxes3d)
+    m, n = boxes3d.shape[0], pts.shape[0]
+    flag = np.empty((m, n), dtype=np.int64)
+    lib().oracle_pts_in_boxes3d(_p(flag), _p(pts), _p(boxes3d), _L(m), _L(n))
+    return flag
+
+
+def roipool3d_cpu(pts, boxes3d, pts_feature, sampled_pts_num):
+    pts, boxes3d, pts_feature = _f32(pts), _f32(boxes3d), _f32(pts_feature)
+    m, n, c = boxes3d.shape[0], pts.shape[0], pts_feature.shape[1]
+    pooled_pts = np.zeros((m, sampled_pts_num, 3), dtype=np.float32)
+    pooled_feat = np.zeros((m, sampled_pts_num, c), dtype=np.float32)
+    flag = np.zeros((m,), dtype=np.int64)
+    lib().oracle_roipool3d_cpu(_p(pts), _p(boxes3d), _p(pts_feature), _p(pooled_pts), _p(pooled_feat), _p(flag),
+                               _L(m), _L(n), _L(c), _L(sampled_pts_num))
+    return pooled_pts, pooled_feat, flag

@@ -1,0 +1,117 @@
+"""TEST INFRASTRUCTURE: extension stand-ins backed by the CPU oracle, operating on CPU torch tensors.
+
+Used (a) by tests/golden/make_golden.py to run the REFERENCE's Python surface on the CPU and (b) by
+tests/test_surface_cpu.py to run epnet_amd's OWN Python surface on the CPU runner, so that the
+composition logic (not the kernels) is checked against the fixtures without a GPU. Never imported by
+the product.
+"""
+import sys
+import types
+
+import numpy as np
+import torch
+
+from oracle import oracle
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def make_modules():
+    """returns (pointnet2_cuda, iou3d_cuda, roipool3d_cuda) look-alikes"""
+    def wr(t, arr):
+        t.copy_(torch.from_numpy(np.ascontiguousarray(arr)).view_as(t))
+
+    p2 = types.ModuleType("pointnet2_cuda")
+
+    def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
+        wr(idx, oracle.ball_query(radius, nsample, _np(xyz), _np(new_xyz)))
+        return 1
+
+    def group_points_wrapper(b, c, n, npoints, nsample, points, idx, out):
+        wr(out, oracle.group_points(_np(points), _np(idx)))
+        return 1
+
+    def group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_points):
+        wr(grad_points, _np(grad_points) + oracle.group_points_grad(_np(grad_out), _np(idx), n))
+        return 1
+
+    def gather_points_wrapper(b, c, n, npoints, points, idx, out):
+        wr(out, oracle.gather_points(_np(points), _np(idx)))
+        return 1
+
+    def gather_points_grad_wrapper(b, c, n, npoints, grad_out, idx, grad_points):
+        wr(grad_points, _np(grad_points) + oracle.gather_points_grad(_np(grad_out), _np(idx), n))
+        return 1
+
+    def furthest_point_sampling_wrapper(b, n, m, points, temp, idx):
+        wr(idx, oracle.furthest_point_sampling(_np(points), m))
+        return 1
+
+    def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
+        d, i = oracle.three_nn(_np(unknown), _np(known))
+        wr(dist2, d)
+        wr(idx, i)
+
+    def three_interpolate_wrapper(b, c, m, n, points, idx, weight, out):
+        wr(out, oracle.three_interpolate(_np(points), _np(idx), _np(weight)))
+
+    def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_points):
+        wr(grad_points, _np(grad_points) + oracle.three_interpolate_grad(_np(grad_out), _np(idx), _np(weight), m))
+
+    for f in (ball_query_wrapper, group_points_wrapper, group_points_grad_wrapper, gather_points_wrapper,
+              gather_points_grad_wrapper, furthest_point_sampling_wrapper, three_nn_wrapper,
+              three_interpolate_wrapper, three_interpolate_grad_wrapper):
+        setattr(p2, f.__name__, f)
+
+    iou = types.ModuleType("iou3d_cuda")
+
+    def boxes_overlap_bev_gpu(a, b, ans):
+        wr(ans, oracle.boxes_overlap_bev(_np(a), _np(b)))
+        return 1
+
+    def boxes_iou_bev_gpu(a, b, ans):
+        wr(ans, oracle.boxes_iou_bev(_np(a), _np(b)))
+        return 1
+
+    def nms_gpu(boxes, keep, thresh):
+        k = oracle.nms(_np(boxes), thresh, True)
+        keep[:len(k)] = torch.from_numpy(k)
+        return len(k)
+
+    def nms_normal_gpu(boxes, keep, thresh):
+        k = oracle.nms(_np(boxes), thresh, False)
+        keep[:len(k)] = torch.from_numpy(k)
+        return len(k)
+
+    def nms_device(boxes, thresh):  # epnet_amd.iou3d_cuda's all-device form
+        k = oracle.nms(_np(boxes), thresh, True)
+        return torch.from_numpy(k), torch.tensor([len(k)], dtype=torch.int32)
+
+    def nms_normal_device(boxes, thresh):
+        k = oracle.nms(_np(boxes), thresh, False)
+        return torch.from_numpy(k), torch.tensor([len(k)], dtype=torch.int32)
+
+    for f in (boxes_overlap_bev_gpu, boxes_iou_bev_gpu, nms_gpu, nms_normal_gpu, nms_device, nms_normal_device):
+        setattr(iou, f.__name__, f)
+
+    rp = types.ModuleType("roipool3d_cuda")
+
+    def forward(xyz, boxes3d, pts_feature, pooled_features, pooled_empty_flag):
+        pooled, flag = oracle.roipool3d(_np(xyz), _np(boxes3d), _np(pts_feature), pooled_features.size(2))
+        wr(pooled_features, pooled)
+        wr(pooled_empty_flag, flag)
+        return 1
+
+    rp.forward = forward
+    return p2, iou, rp
+
+
+def install_as_top_level():
+    p2, iou, rp = make_modules()
+    sys.modules["pointnet2_cuda"] = p2
+    sys.modules["iou3d_cuda"] = iou
+    sys.modules["roipool3d_cuda"] = rp
+
+

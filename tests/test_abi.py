@@ -1,0 +1,82 @@
+"""The C-ABI library: loads without a GPU, exports every symbol include/epnet_ops.h declares, and the
+Python binding table mirrors the header. No compute calls here (there is no GPU on the CPU runner)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "epnet_ops.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(epnet_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_hot_path():
+    names = header_functions()
+    for must in ["epnet_furthest_point_sampling", "epnet_gather_points", "epnet_gather_points_grad", "epnet_ball_query",
+                 "epnet_group_points", "epnet_group_points_grad", "epnet_three_nn", "epnet_three_interpolate",
+                 "epnet_three_interpolate_grad", "epnet_boxes_overlap_bev", "epnet_boxes_iou_bev", "epnet_nms",
+                 "epnet_nms_normal", "epnet_roipool3d", "epnet_pts_in_boxes3d_host", "epnet_roipool3d_host"]:
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol(hiplib):
+    from epnet_amd import _lib
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in header_functions():
+        assert hasattr(raw, name), "libepnet_hip.so lacks %s" % name
+    assert sorted(_lib.SIGNATURES) == header_functions()
+    assert hiplib.epnet_abi_version() == 1
+    assert hiplib.epnet_strerror(0) == b"ok" and b"workspace" in hiplib.epnet_strerror(-3)
+
+
+def test_argument_validation_without_gpu(hiplib):
+    # negative sizes / NULL pointers are rejected before anything touches the device
+    assert hiplib.epnet_ball_query(-1, 1, 1, 1.0, 1, None, None, None, None) == -1
+    assert hiplib.epnet_furthest_point_sampling(1, 16, 4, None, None, None, None) == -1
+    assert hiplib.epnet_group_points(1, 1, 1, 1, 1, None, None, None, None) == -1
+    assert hiplib.epnet_nms_workspace_bytes(6300) == 6300 * 99 * 8
+    assert hiplib.epnet_nms_workspace_bytes(0) == 0
+    # empty problems are no-ops
+    assert hiplib.epnet_ball_query(0, 10, 10, 1.0, 4, None, None, None, None) == 0
+    assert hiplib.epnet_three_nn(1, 0, 5, None, None, None, None, None) == 0
+
+
+def test_missing_library_is_loud(monkeypatch, tmp_path):
+    from epnet_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.lib()
+
+
+def test_cpu_tensors_are_rejected(hiplib):
+    import torch
+    from epnet_amd import pointnet2_utils, iou3d_utils
+    xyz = torch.zeros((1, 8, 3))
+    with pytest.raises(RuntimeError, match="CUDAtensor"):
+        pointnet2_utils.ball_query(1.0, 4, xyz, xyz)
+    with pytest.raises(RuntimeError, match="CUDAtensor"):
+        iou3d_utils.boxes_iou_bev(torch.zeros((2, 5)), torch.zeros((2, 5)))
+
+
+def test_host_ops_match_oracle_and_fixture(hiplib, oracle):
+    """roipool3d's CPU entry points are host ops in the reference too (roipool3d.cpp:97-195)"""
+    import numpy as np
+    import torch
+    from conftest import golden
+    from epnet_amd import roipool3d_utils
+    fx = golden("roipool3d_ref.npz")
+    n = fx["pts"].shape[0]
+    masks = roipool3d_utils.pts_in_boxes3d_cpu(torch.from_numpy(fx["pts"]), torch.from_numpy(fx["boxes3d"]))
+    flags = np.unpackbits(fx["pts_flag"], axis=1)[:, :n].astype(bool)
+    np.testing.assert_array_equal(torch.stack(masks).numpy(), flags)
+    pp, pf, ef = roipool3d_utils.roipool_pc_cpu(torch.from_numpy(fx["pts"]), torch.from_numpy(fx["pts_feature"]),
+                                               torch.from_numpy(fx["boxes3d"]), fx["pooled_pts"].shape[1])
+    np.testing.assert_array_equal(pp.numpy(), fx["pooled_pts"])
+    np.testing.assert_array_equal(pf.numpy(), fx["pooled_features"])
+    np.testing.assert_array_equal(ef.numpy(), fx["pooled_empty_flag"])
