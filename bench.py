@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""bench.py -- SA-stack points/s per GPU on synthetic KITTI-shaped scenes (BASELINE.json's metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--kind kitti|ubox|dup] [--no-graph]
+
+One "step" = one pass of the 4-level set-abstraction OPERATOR stack (4 FPS + 4 gather + 8 ball_query +
+14 grouping calls, epnet_amd/sa_stack.py) over a batch of B independent 16384-point scenes that are
+already resident in HBM. N > 1: launched by torch.distributed.run, one rank per GPU; every rank owns its
+own scenes (different seeds), there is NO collective in the data path (the ops are independent per
+scene), so scaling is "weak". Timing: barrier + synchronize on both sides of exactly K steps, MAX over
+ranks; rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline      the kernel with the largest share of the step (furthest point sampling), priced by its
+                ALGORITHMIC bytes per launch / its average duration measured with HIP events on the
+                launch stream over an instrumented replay of the same K steps; `kernels` lists the same
+                figure for every op family (the grouping kernels are the bandwidth-bound ones).
+  cpu_baseline  the CPU oracle (a scalar C port of the reference kernels, 1 core) timed on this host on
+                a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("EPNET_BENCH_BATCH", "16")),
+                    help="scenes per GPU per step")
+    ap.add_argument("--points", type=int, default=16384)
+    ap.add_argument("--kind", default="kitti", choices=["kitti", "ubox", "dup"])
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--with-fp", action="store_true", help="also run the 4 three_nn + 4 three_interpolate FP ops")
+    ap.add_argument("--cpu-scenes", type=int, default=int(os.environ.get("EPNET_BENCH_CPU_SCENES", "16")),
+                    help="scenes in the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--sweep", default="", help="comma list of extra batch sizes to time (reported under 'sweep')")
+    return ap.parse_args()
+
+
+def cpu_baseline(kind, n_points, scenes):
+    """the oracle's scalar port of the same op stack, one core, on `scenes` scenes"""
+    import numpy as np
+    from epnet_amd import sa_stack, synth
+    from oracle import oracle
+    oracle.build()
+    rng = np.random.default_rng(0)
+    t_total = 0.0
+    for s in range(scenes):
+        xyz = synth.scenes(kind, 1, n_points, seed=1000 + s).numpy()
+        feats = [None if c == 0 else rng.standard_normal((1, c, nn)).astype(np.float32)
+                 for c, nn in zip(sa_stack.RPN_FEAT_CHANNELS, (n_points,) + sa_stack.RPN_NPOINTS[:-1])]
+        t0 = time.perf_counter()
+        cur = xyz
+        for lvl, m in enumerate(sa_stack.RPN_NPOINTS):
+            cur_t = np.ascontiguousarray(cur.transpose(0, 2, 1))
+            idx = oracle.furthest_point_sampling(cur, m)
+            new_xyz = np.ascontiguousarray(oracle.gather_points(cur_t, idx).transpose(0, 2, 1))
+            for radius, ns in zip(sa_stack.RPN_RADII[lvl], sa_stack.RPN_NSAMPLES[lvl]):
+                bq = oracle.ball_query(radius, ns, cur, new_xyz)
+                oracle.group_points(cur_t, bq)
+                if feats[lvl] is not None:
+                    oracle.group_points(feats[lvl], bq)
+            cur = new_xyz
+        t_total += time.perf_counter() - t0
+    return {"value": scenes * n_points / t_total, "unit": "points/s", "cores": 1, "kind": "port",
+            "sample": "%d %s scenes of %d points through the same 4-level SA op stack, oracle/epnet_oracle.c, "
+                      "%.1f s of CPU time on %d-core host" % (scenes, kind, n_points, t_total, os.cpu_count())}
+
+
+class OpTimer:
+    """wraps the extension stand-in's functions with HIP event pairs recorded on the launch stream"""
+
+    def __init__(self, torch, ext):
+        self.torch, self.ext, self.records, self.saved = torch, ext, [], {}
+
+    def __enter__(self):
+        for name in [n for n in dir(self.ext) if n.endswith("_wrapper")]:
+            fn = getattr(self.ext, name)
+            self.saved[name] = fn
+
+            def timed(*a, _fn=fn, _name=name):
+                dev = next(x for x in a if hasattr(x, "is_cuda")).device
+                stream = self.torch.cuda.current_stream(dev)
+                e0 = self.torch.cuda.Event(enable_timing=True)
+                e1 = self.torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                r = _fn(*a)
+                e1.record(stream)
+                self.records.append((_name, a[:5], e0, e1))
+                return r
+
+            setattr(self.ext, name, timed)
+        return self
+
+    def __exit__(self, *exc):
+        for name, fn in self.saved.items():
+            setattr(self.ext, name, fn)
+        return False
+
+
+def op_family(name, head):
+    """(family label, algorithmic bytes of this launch) -- formulas of SURVEY.md section 8(d)"""
+    if name.startswith("furthest"):
+        b, n, m = head[:3]
+        return "fps N=%d M=%d" % (n, m), b * (n * 12 + m * 4)
+    if name.startswith("gather_points_w"):
+        b, c, n, m = head[:4]
+        return "gather", b * (m * 4 + c * n * 4 + c * m * 4)
+    if name.startswith("ball_query"):
+        b, n, m, _r, ns = head[:5]
+        return "ball_query", b * (n * 12 + m * 12 + m * ns * 4)
+    if name.startswith("group_points_w"):
+        b, c, n, m, ns = head[:5]
+        return ("group_xyz" if c == 3 else "group_feat"), b * (m * ns * 4 + c * n * 4 + c * m * ns * 4)
+    if name.startswith("three_nn"):
+        b, n, m = head[:3]
+        return "three_nn", b * (n * 12 + m * 12 + n * 24)
+    if name.startswith("three_interpolate_w"):
+        b, c, m, n = head[:4]
+        return "three_interpolate", b * (c * m * 4 + n * 24 + c * n * 4)
+    return name, 0
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from epnet_amd import _lib, pointnet2_cuda as ext, sa_stack, synth
+    _lib.lib()  # fail loudly if the HIP library is missing
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def time_stack(batch, steps, warmup):
+        """returns (seconds for `steps` steps, the stack, its input)"""
+        xyz = synth.scenes(args.kind, batch, args.points, seed=1 + rank * 100003).to(dev)   # inputs resident in HBM
+        stack = sa_stack.SAStack(batch, n=args.points, device=dev, with_fp=args.with_fp, seed=rank)
+        if args.no_graph:
+            step = lambda: stack.run(xyz)
+        else:
+            stack.capture(xyz)
+            step = stack.replay
+        for _ in range(warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        return time.perf_counter() - t0, stack, xyz
+
+    elapsed, stack, xyz = time_stack(args.batch, args.steps, args.warmup)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    points_per_step = world * args.batch * args.points
+    value = points_per_step * args.steps / elapsed
+
+    # ---- per-kernel durations: the same K steps replayed eagerly with HIP events around every launch
+    with OpTimer(torch, ext) as timer:
+        for _ in range(args.steps):
+            stack.run(xyz)
+        torch.cuda.synchronize()
+    fam = {}
+    for name, head, e0, e1 in timer.records:
+        label, nbytes = op_family(name, head)
+        f = fam.setdefault(label, {"ms": 0.0, "bytes": 0, "launches": 0})
+        f["ms"] += e0.elapsed_time(e1)
+        f["bytes"] += nbytes
+        f["launches"] += 1
+    kernels = {}
+    for label, f in fam.items():
+        avg_ms = f["ms"] / f["launches"]
+        gbs = (f["bytes"] / f["launches"]) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        kernels[label] = {"launches_per_step": f["launches"] // args.steps, "avg_ms": round(avg_ms, 5),
+                          "step_ms": round(f["ms"] / args.steps, 5),
+                          "bytes_per_launch": f["bytes"] // f["launches"], "GBps": round(gbs, 2)}
+    dominant = max(kernels, key=lambda k: kernels[k]["step_ms"])
+    dk = kernels[dominant]
+    roofline = {"bound": "hbm", "kernel": dominant, "achieved": dk["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(dk["GBps"] / HBM_PEAK_GBS, 6), "traffic": None,
+                "note": "FPS is a chain of M-1 dependent arg-max iterations per scene (latency bound), one workgroup "
+                        "per scene; the bandwidth-bound kernels are group_feat/group_xyz, see 'kernels'"}
+    stack_bytes = sa_stack.sa_algorithmic_bytes(args.points)["total"] + (sa_stack.fp_algorithmic_bytes()["total"] if args.with_fp else 0)
+    stack_gbs = (value / args.points) * stack_bytes / 1e9 / world
+
+    sweep = {}
+    for bsz in [int(x) for x in args.sweep.split(",") if x]:
+        e, _, _ = time_stack(bsz, args.steps, args.warmup)
+        sweep[str(bsz)] = {"ms_per_step": round(e / args.steps * 1e3, 4), "points_per_s": round(bsz * args.points * args.steps / e, 1)}
+
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_scenes > 0:
+        cpu = cpu_baseline(args.kind, args.points, args.cpu_scenes)
+
+    if rank == 0:
+        line = {
+            "metric": "SA-stack points/sec per GPU (16384-pt KITTI scene) + % HBM roofline",
+            "value": round(value, 1), "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%d x %d-pt %s scenes per GPU per step through the 4-level SA op stack "
+                                   "(4 FPS + 4 gather + 8 ball_query + 14 grouping%s), pyramid 16384>4096>1024>256>64, "
+                                   "radii [[.1,.5],[.5,1],[1,2],[2,4]], nsample [16,32], C=0/96/256/512, %s launch"
+                                   % (args.batch, args.points, args.kind, " + 4 three_nn + 4 three_interpolate" if args.with_fp else "",
+                                      "eager" if args.no_graph else "HIP-graph"),
+                       "scenes_per_gpu": args.batch, "points_per_scene": args.points, "parallelism": "scene-parallel x%d" % world},
+            "points_per_s_per_gpu": round(value / world, 1),
+            "stack_algorithmic_GBps_per_gpu": round(stack_gbs, 2), "stack_hbm_frac": round(stack_gbs / HBM_PEAK_GBS, 6),
+            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+        }
+        if sweep:
+            line["sweep"] = sweep
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

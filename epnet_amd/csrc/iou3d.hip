@@ -257,8 +257,11 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(int boxes_num,
             for (int i = 0; i < 64; ++i) {
                 if ((alive >> i) & 1ull) {  // wave-uniform
                     kept |= 1ull << i;
-                    const unsigned long long row = ((unsigned long long)__builtin_amdgcn_readlane(dhi, i) << 32) |
-                                                   (unsigned long long)__builtin_amdgcn_readlane(dlo, i);
+                    // readlane returns a signed int: go through unsigned, or bit 31 of the low half would
+                    // sign-extend over the whole high half
+                    const unsigned rlo = (unsigned)__builtin_amdgcn_readlane((int)dlo, i);
+                    const unsigned rhi = (unsigned)__builtin_amdgcn_readlane((int)dhi, i);
+                    const unsigned long long row = ((unsigned long long)rhi << 32) | (unsigned long long)rlo;
                     alive &= ~row;
                 }
             }

@@ -1,0 +1,427 @@
+"""Parity tests proper: the HIP path (called through the extension stand-ins, i.e. through the C ABI)
+against the CPU oracle on the same seeded inputs, against the committed golden fixtures, and -- at
+BASELINE.json's full sizes -- through size-independent properties.
+
+Bar: bit-exact for indices / masks / flags and for pure copies; <= 1e-5 for float sums whose order the
+reference itself leaves unspecified (atomic scatter-adds) and for the trig-dependent rotated IoU.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib_loaded(hiplib):
+    assert torch.cuda.is_available()
+    return hiplib
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def rand_cloud(b, n, seed, kind="kitti"):
+    from epnet_amd import synth
+    return synth.scenes(kind, b, n, seed=seed).numpy()
+
+
+# ------------------------------------------------------------------------------------------------ FPS
+
+@pytest.mark.parametrize("b,n,m,kind", [
+    (2, 4096, 1024, "ubox"),     # BASELINE config 1 shape, x2 scenes
+    (1, 16384, 4096, "kitti"),   # level 1 of the RPN pyramid (16 points / thread, register resident)
+    (2, 16384, 512, "dup"),      # duplicated rows at full width
+    (3, 1024, 256, "kitti"),     # level 3
+    (4, 256, 64, "kitti"),       # level 4
+    (8, 512, 128, "dup"),        # RCNN-stage shape (512-pt ROI clouds), ties from padding
+    (2, 1000, 300, "kitti"),     # non power of two: reference block size 512, 2 points / thread
+    (2, 100, 40, "ubox"),        # block size 64
+    (3, 37, 20, "ubox"),         # reference block size 32 < one wave
+    (2, 3, 3, "ubox"), (1, 2, 2, "ubox"), (2, 1, 1, "ubox"),
+    (1, 5000, 1, "ubox"),        # m = 1: only index 0
+])
+def test_fps_matches_oracle(oracle, b, n, m, kind):
+    from epnet_amd import pointnet2_utils as p2u
+    xyz = rand_cloud(b, n, seed=100 + n, kind=kind)
+    got = host(p2u.furthest_point_sample(dev(xyz), m))
+    np.testing.assert_array_equal(got, oracle.furthest_point_sampling(xyz, m))
+
+
+def test_fps_ties_all_equal_and_heavy_duplicates(oracle):
+    from epnet_amd import pointnet2_utils as p2u
+    ones = np.ones((2, 2048, 3), np.float32)
+    np.testing.assert_array_equal(host(p2u.furthest_point_sample(dev(ones), 7)), oracle.furthest_point_sampling(ones, 7))
+    # 16 distinct points repeated 128 times, more picks than distinct points
+    rng = np.random.default_rng(5)
+    base = rng.standard_normal((16, 3)).astype(np.float32)
+    xyz = base[rng.integers(0, 16, size=(2, 2048))]
+    np.testing.assert_array_equal(host(p2u.furthest_point_sample(dev(xyz), 100)), oracle.furthest_point_sampling(xyz, 100))
+    # integer lattice: many exact distance ties between distinct points
+    g = np.stack(np.meshgrid(np.arange(16), np.arange(16), np.arange(8), indexing="ij"), -1).reshape(1, -1, 3).astype(np.float32)
+    np.testing.assert_array_equal(host(p2u.furthest_point_sample(dev(g), 512)), oracle.furthest_point_sampling(g, 512))
+
+
+def test_fps_running_distance_buffer_and_streaming_path(oracle):
+    """temp is an in/out buffer of the extension (sampling.cpp:36-46); n > 16384 takes the streaming kernel"""
+    from epnet_amd import pointnet2_cuda as ext
+    for n, m in ((4096, 200), (20000, 48)):
+        xyz = rand_cloud(2, n, seed=7, kind="kitti")
+        temp = torch.full((2, n), 1e10, device=DEV)
+        idx = torch.empty((2, m), dtype=torch.int32, device=DEV)
+        ext.furthest_point_sampling_wrapper(2, n, m, dev(xyz), temp, idx)
+        o_idx, o_temp = oracle.furthest_point_sampling(xyz, m, return_temp=True)
+        np.testing.assert_array_equal(host(idx), o_idx)
+        np.testing.assert_array_equal(host(temp), o_temp)
+
+
+def test_fps_golden_fixtures():
+    from epnet_amd import pointnet2_utils as p2u
+    fx = golden("pointnet2_cfg1.npz")
+    np.testing.assert_array_equal(host(p2u.furthest_point_sample(dev(fx["xyz"]), 1024)), fx["fps_idx"])
+    ft = golden("fps_ties.npz")
+    np.testing.assert_array_equal(host(p2u.furthest_point_sample(dev(ft["dup_xyz"]), 1500)), ft["dup_idx"])
+    np.testing.assert_array_equal(host(p2u.furthest_point_sample(dev(ft["odd_xyz"]), 300)), ft["odd_idx"])
+
+
+def test_fps_full_size_properties():
+    """B = 16 scenes of 16384 points -> 4096: index 0 first, all indices distinct (the clouds have no
+    duplicate rows), and the greedy max-min property holds for the sequence (checked in float64 on a
+    prefix: each pick maximises the distance to the picks before it, up to fp32 rounding)."""
+    from epnet_amd import pointnet2_utils as p2u
+    xyz = rand_cloud(16, 16384, seed=50, kind="ubox")
+    idx = host(p2u.furthest_point_sample(dev(xyz), 4096))
+    assert (idx[:, 0] == 0).all() and idx.min() >= 0 and idx.max() < 16384
+    for b in range(16):
+        assert len(np.unique(idx[b])) == 4096
+    p = xyz[3].astype(np.float64)
+    d = np.full(16384, np.inf)
+    for j in range(1, 64):
+        d = np.minimum(d, ((p - p[idx[3, j - 1]]) ** 2).sum(1))
+        assert d[idx[3, j]] >= d.max() * (1 - 1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ ball query
+
+@pytest.mark.parametrize("b,n,m,radius,ns,kind", [
+    (1, 4096, 1024, 0.1, 32, "ubox"), (1, 4096, 1024, 2.0, 32, "ubox"),
+    (2, 16384, 4096, 0.1, 16, "kitti"), (2, 16384, 4096, 0.5, 32, "kitti"),
+    (2, 4096, 1024, 0.5, 16, "kitti"), (2, 4096, 1024, 1.0, 32, "kitti"),
+    (2, 1024, 256, 1.0, 16, "kitti"), (2, 1024, 256, 2.0, 32, "kitti"),
+    (2, 256, 64, 2.0, 16, "kitti"), (2, 256, 64, 4.0, 32, "kitti"),
+    (16, 512, 128, 0.2, 64, "kitti"), (16, 128, 32, 0.4, 64, "kitti"),   # RCNN stage
+    (3, 1000, 77, 1.5, 5, "kitti"), (2, 2100, 9, 3.0, 70, "kitti"), (1, 63, 3, 50.0, 8, "ubox"),
+    (1, 5000, 13, 100.0, 128, "ubox"),                                   # every ball saturates at once
+])
+def test_ball_query_matches_oracle(oracle, b, n, m, radius, ns, kind):
+    from epnet_amd import pointnet2_utils as p2u
+    xyz = rand_cloud(b, n, seed=200 + n + m, kind=kind)
+    centres = np.ascontiguousarray(xyz[:, np.random.default_rng(n).permutation(n)[:m]])
+    if kind == "ubox":
+        centres[:, -1] = 1e4  # one empty ball per scene -> all-zero row
+    got = host(p2u.ball_query(radius, ns, dev(xyz), dev(centres)))
+    np.testing.assert_array_equal(got, oracle.ball_query(radius, ns, xyz, centres))
+
+
+def test_ball_query_writes_every_slot_and_boundary_is_strict(oracle):
+    from epnet_amd import pointnet2_cuda as ext
+    xyz = np.zeros((1, 130, 3), np.float32)
+    xyz[0, :, 0] = np.arange(130)
+    centres = np.array([[[64.0, 0, 0], [1000.0, 0, 0]]], np.float32)
+    idx = torch.full((1, 2, 6), -7, dtype=torch.int32, device=DEV)      # garbage in: must be overwritten
+    ext.ball_query_wrapper(1, 130, 2, 2.0, 6, dev(centres), dev(xyz), idx)
+    assert host(idx).tolist() == [[[63, 64, 65, 63, 63, 63], [0, 0, 0, 0, 0, 0]]]
+
+
+def test_ball_query_full_size_property():
+    """config 5 shape on a reduced batch: 65536 points, 16384 centres, nsample 64: every index lies in
+    the ball or is the padding value, and the hits are strictly increasing."""
+    from epnet_amd import pointnet2_utils as p2u
+    xyz = rand_cloud(1, 65536, seed=9, kind="kitti")
+    centres = np.ascontiguousarray(xyz[:, ::4])
+    idx = host(p2u.ball_query(0.5, 64, dev(xyz), dev(centres)))[0]
+    d2 = ((xyz[0][idx] - centres[0][:, None, :]) ** 2).sum(-1)
+    assert (d2 < 0.25 + 1e-6).all()                      # every centre is a cloud point -> no empty ball
+    first = idx[:, :1]
+    inc = (np.diff(idx, axis=1) > 0) | (idx[:, 1:] == first)
+    assert inc.all()
+
+
+# ------------------------------------------------------------------------------------------------ gathers
+
+@pytest.mark.parametrize("b,c,n,m,ns", [(2, 3, 4096, 1024, 16), (2, 96, 4096, 1024, 32), (1, 256, 1024, 256, 16),
+                                        (2, 17, 333, 21, 5), (1, 1, 64, 7, 3), (4, 128, 512, 128, 64)])
+def test_group_points_exact(oracle, b, c, n, m, ns):
+    from epnet_amd import pointnet2_utils as p2u
+    rng = np.random.default_rng(c * n)
+    feats = rng.standard_normal((b, c, n)).astype(np.float32)
+    idx = rng.integers(0, n, size=(b, m, ns)).astype(np.int32)
+    np.testing.assert_array_equal(host(p2u.grouping_operation(dev(feats), dev(idx))), oracle.group_points(feats, idx))
+
+
+@pytest.mark.parametrize("b,c,n,m", [(2, 3, 16384, 4096), (2, 3, 4096, 1024), (3, 5, 100, 33)])
+def test_gather_points_exact(oracle, b, c, n, m):
+    from epnet_amd import pointnet2_utils as p2u
+    rng = np.random.default_rng(n + m)
+    feats = rng.standard_normal((b, c, n)).astype(np.float32)
+    idx = rng.integers(0, n, size=(b, m)).astype(np.int32)
+    np.testing.assert_array_equal(host(p2u.gather_operation(dev(feats), dev(idx))), oracle.gather_points(feats, idx))
+
+
+def test_group_full_size_against_torch():
+    """level-2 feature grouping at B = 8 (C=96, N=4096, M=1024, ns=32): equals a torch.gather"""
+    from epnet_amd import pointnet2_utils as p2u
+    g = torch.Generator().manual_seed(3)
+    feats = torch.randn((8, 96, 4096), generator=g).to(DEV)
+    idx = torch.randint(0, 4096, (8, 1024, 32), generator=g, dtype=torch.int32).to(DEV)
+    out = p2u.grouping_operation(feats, idx)
+    ref = torch.gather(feats, 2, idx.view(8, 1, -1).expand(-1, 96, -1).long()).view(8, 96, 1024, 32)
+    assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("b,c,n,m,ns", [(2, 96, 4096, 1024, 32), (2, 5, 333, 21, 5), (1, 3, 20000, 100, 8), (2, 256, 256, 64, 16)])
+def test_group_points_grad(oracle, b, c, n, m, ns):
+    from epnet_amd import pointnet2_cuda as ext
+    rng = np.random.default_rng(7 * c + n)
+    go = rng.standard_normal((b, c, m, ns)).astype(np.float32)
+    idx = rng.integers(0, n, size=(b, m, ns)).astype(np.int32)
+    grad = torch.zeros((b, c, n), device=DEV)
+    ext.group_points_grad_wrapper(b, c, n, m, ns, dev(go), dev(idx), grad)
+    np.testing.assert_allclose(host(grad), oracle.group_points_grad(go, idx, n), rtol=1e-5, atol=1e-5)
+
+
+def test_gather_points_grad_and_accumulation(oracle):
+    from epnet_amd import pointnet2_cuda as ext
+    rng = np.random.default_rng(11)
+    go = rng.standard_normal((2, 3, 500)).astype(np.float32)
+    idx = rng.integers(0, 2000, size=(2, 500)).astype(np.int32)
+    grad = torch.ones((2, 3, 2000), device=DEV)  # the kernel accumulates INTO the buffer, like atomicAdd does
+    ext.gather_points_grad_wrapper(2, 3, 2000, 500, dev(go), dev(idx), grad)
+    np.testing.assert_allclose(host(grad), 1 + oracle.gather_points_grad(go, idx, 2000), rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ interpolation
+
+@pytest.mark.parametrize("b,n,m", [(2, 256, 64), (2, 1024, 256), (2, 4096, 1024), (1, 16384, 4096), (3, 77, 13), (2, 40, 5000)])
+def test_three_nn_matches_oracle(oracle, b, n, m):
+    from epnet_amd import pointnet2_cuda as ext
+    unknown = rand_cloud(b, n, seed=n, kind="kitti")
+    known = np.ascontiguousarray(rand_cloud(b, max(m, 8), seed=n + 1, kind="kitti")[:, :m])
+    d2 = torch.empty((b, n, 3), device=DEV)
+    idx = torch.empty((b, n, 3), dtype=torch.int32, device=DEV)
+    ext.three_nn_wrapper(b, n, m, dev(unknown), dev(known), d2, idx)
+    o_d2, o_idx = oracle.three_nn(unknown, known)
+    np.testing.assert_array_equal(host(idx), o_idx)
+    np.testing.assert_array_equal(host(d2), o_d2)
+
+
+def test_three_nn_ties_and_short_known(oracle):
+    from epnet_amd import pointnet2_cuda as ext
+    rng = np.random.default_rng(2)
+    base = rng.standard_normal((6, 3)).astype(np.float32)
+    known = base[rng.integers(0, 6, size=(2, 100))]            # heavy duplicates: distance ties everywhere
+    unknown = rng.standard_normal((2, 50, 3)).astype(np.float32)
+    for m in (100, 9, 2, 1):
+        kn = np.ascontiguousarray(known[:, :m])
+        d2 = torch.empty((2, 50, 3), device=DEV)
+        idx = torch.empty((2, 50, 3), dtype=torch.int32, device=DEV)
+        ext.three_nn_wrapper(2, 50, m, dev(unknown), dev(kn), d2, idx)
+        o_d2, o_idx = oracle.three_nn(unknown, kn)
+        np.testing.assert_array_equal(host(idx), o_idx)
+        np.testing.assert_array_equal(host(d2), o_d2)            # inf in the unfilled slots when m < 3
+
+
+@pytest.mark.parametrize("b,c,m,n", [(2, 256, 64, 256), (2, 128, 1024, 4096), (1, 7, 50, 333), (2, 16, 9, 2)])
+def test_three_interpolate_and_grad(oracle, b, c, m, n):
+    from epnet_amd import pointnet2_cuda as ext
+    rng = np.random.default_rng(c + m)
+    pts = rng.standard_normal((b, c, m)).astype(np.float32)
+    idx = rng.integers(0, m, size=(b, n, 3)).astype(np.int32)
+    w = rng.random((b, n, 3)).astype(np.float32)
+    w /= w.sum(-1, keepdims=True)
+    out = torch.empty((b, c, n), device=DEV)
+    ext.three_interpolate_wrapper(b, c, m, n, dev(pts), dev(idx), dev(w), out)
+    np.testing.assert_array_equal(host(out), oracle.three_interpolate(pts, idx, w))   # same op order, no contraction
+    go = rng.standard_normal((b, c, n)).astype(np.float32)
+    grad = torch.zeros((b, c, m), device=DEV)
+    ext.three_interpolate_grad_wrapper(b, c, n, m, dev(go), dev(idx), dev(w), grad)
+    np.testing.assert_allclose(host(grad), oracle.three_interpolate_grad(go, idx, w, m), rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ iou3d
+
+def boxes_bev(num, seed):
+    from epnet_amd import kitti_utils, synth
+    b, s = synth.proposal_boxes(num, seed=seed, num_objects=max(4, num // 20), jitter=0.8)
+    return kitti_utils.boxes3d_to_bev_torch(b).numpy(), s.numpy(), b.numpy()
+
+
+def test_rotated_overlap_and_iou(oracle):
+    from epnet_amd import iou3d_cuda as ext
+    a, _, _ = boxes_bev(150, 1)
+    b, _, _ = boxes_bev(37, 2)
+    for fn, ofn in ((ext.boxes_overlap_bev_gpu, oracle.boxes_overlap_bev), (ext.boxes_iou_bev_gpu, oracle.boxes_iou_bev)):
+        ans = torch.zeros((150, 37), device=DEV)
+        fn(dev(a), dev(b), ans)
+        ref = ofn(a, b)
+        np.testing.assert_allclose(host(ans), ref, rtol=0, atol=1e-5)
+        assert (ref > 0).sum() > 50
+    # analytic cases (same as the oracle's KATs)
+    unit = np.array([[0, 0, 1, 1, 0]], np.float32)
+    rot = np.array([[0, 0, 1, 1, np.pi / 4]], np.float32)
+    ans = torch.zeros((1, 1), device=DEV)
+    ext.boxes_overlap_bev_gpu(dev(unit), dev(rot), ans)
+    assert ans.item() == pytest.approx(2 * (2 ** 0.5 - 1), abs=1e-5)
+    ext.boxes_iou_bev_gpu(dev(unit), dev(unit), ans)
+    assert ans.item() == pytest.approx(1.0, abs=1e-6)
+
+
+def test_iou3d_surface_fixture():
+    from epnet_amd import iou3d_utils, kitti_utils
+    fx = golden("iou3d.npz")
+    a, b, s = dev(fx["boxes_a"]), dev(fx["boxes_b"]), dev(fx["scores"])
+    np.testing.assert_allclose(host(iou3d_utils.boxes_iou3d_gpu(a, b)), fx["iou3d"], rtol=0, atol=1e-5)
+    bev_a, bev_b = kitti_utils.boxes3d_to_bev_torch(a), kitti_utils.boxes3d_to_bev_torch(b)
+    np.testing.assert_allclose(host(iou3d_utils.boxes_iou_bev(bev_a, bev_b)), fx["iou_bev"], rtol=0, atol=1e-5)
+    for key, thr, fn in (("keep_rot_010", 0.1, iou3d_utils.nms_gpu), ("keep_rot_050", 0.5, iou3d_utils.nms_gpu),
+                         ("keep_normal_085", 0.85, iou3d_utils.nms_normal_gpu), ("keep_normal_050", 0.5, iou3d_utils.nms_normal_gpu)):
+        kept = fn(bev_a, s, thr)
+        assert kept.dtype == torch.int64 and kept.is_cuda
+        np.testing.assert_array_equal(host(kept), fx[key])
+
+
+@pytest.mark.parametrize("n,thr", [(6300, 0.85), (2700, 0.85), (1000, 0.3), (64, 0.5), (65, 0.5), (1, 0.5)])
+def test_nms_normal_full_size_exact(oracle, n, thr):
+    """the training-path NMS (RPN.NMS_TYPE normal): N up to 6300, no trig -> bit-exact keep list"""
+    from epnet_amd import iou3d_cuda as ext
+    bev, scores, _ = boxes_bev(n, 10 + n)
+    order = np.argsort(-scores, kind="stable")
+    sorted_boxes = np.ascontiguousarray(bev[order])
+    keep = torch.zeros((n,), dtype=torch.int64)
+    num = ext.nms_normal_gpu(dev(sorted_boxes), keep, thr)      # the reference contract: CPU int64 keep + count
+    o_keep = oracle.nms(sorted_boxes, thr, False)
+    assert num == len(o_keep)
+    np.testing.assert_array_equal(keep[:num].numpy(), o_keep)
+
+
+def test_nms_rotated_and_empty(oracle):
+    from epnet_amd import iou3d_cuda as ext
+    bev, scores, _ = boxes_bev(700, 77)
+    sorted_boxes = np.ascontiguousarray(bev[np.argsort(-scores, kind="stable")])
+    full = oracle.boxes_iou_bev(sorted_boxes, sorted_boxes)
+    thr = 0.1
+    while np.abs(full - thr).min() < 1e-5:   # keep the test away from libm-borderline pairs
+        thr += 0.0137
+    keep, num = ext.nms_device(dev(sorted_boxes), thr)
+    n = int(num.item())
+    np.testing.assert_array_equal(host(keep[:n]), oracle.nms(sorted_boxes, thr, True))
+    keep, num = ext.nms_device(torch.zeros((0, 5), device=DEV), 0.5)
+    assert int(num.item()) == 0
+
+
+# ------------------------------------------------------------------------------------------------ roipool3d
+
+def test_roipool3d_fixtures_exact():
+    from epnet_amd import roipool3d_utils
+    fx = golden("roipool3d_surface.npz")
+    pooled, empty = roipool3d_utils.roipool3d_gpu(dev(fx["pts"]), dev(fx["pts_feature"]), dev(fx["boxes3d"]), 0.2, sampled_pt_num=64)
+    np.testing.assert_array_equal(host(empty), fx["pooled_empty_flag"])
+    np.testing.assert_array_equal(host(pooled), fx["pooled_features"])
+    # the fixture captured from the reference's own compiled CPU op (boxes already enlarged there)
+    rf = golden("roipool3d_ref.npz")
+    from epnet_amd import roipool3d_cuda as ext
+    m, s, c = rf["boxes3d"].shape[0], rf["pooled_pts"].shape[1], rf["pts_feature"].shape[1]
+    out = torch.zeros((1, m, s, 3 + c), device=DEV)
+    flag = torch.zeros((1, m), dtype=torch.int32, device=DEV)
+    ext.forward(dev(rf["pts"][None]), dev(rf["boxes3d"][None]), dev(rf["pts_feature"][None]), out, flag)
+    np.testing.assert_array_equal(host(flag)[0], rf["pooled_empty_flag"].astype(np.int32))
+    np.testing.assert_array_equal(host(out)[0, :, :, :3], rf["pooled_pts"])
+    np.testing.assert_array_equal(host(out)[0, :, :, 3:], rf["pooled_features"])
+
+
+@pytest.mark.parametrize("b,n,m,c,s", [(2, 16384, 64, 130, 512), (1, 5000, 7, 1, 33), (2, 700, 3, 0, 16), (1, 100, 2, 5, 600)])
+def test_roipool3d_matches_oracle(oracle, b, n, m, c, s):
+    from epnet_amd import kitti_utils, roipool3d_cuda as ext, synth
+    pts = rand_cloud(b, n, seed=300 + n, kind="kitti")
+    boxes = np.stack([synth.proposal_boxes(m, seed=400 + i, num_objects=40, jitter=0.5)[0].numpy() for i in range(b)])
+    boxes = kitti_utils.enlarge_box3d(boxes.reshape(-1, 7), 0.2).reshape(b, m, 7)
+    boxes[:, -1, 0] = 900.0   # one empty box per scene
+    feat = np.random.default_rng(n).standard_normal((b, n, c)).astype(np.float32)
+    out = torch.zeros((b, m, s, 3 + c), device=DEV)
+    flag = torch.zeros((b, m), dtype=torch.int32, device=DEV)
+    ext.forward(dev(pts), dev(boxes), dev(feat), out, flag)
+    o_pool, o_flag = oracle.roipool3d(pts, boxes, feat, s)
+    np.testing.assert_array_equal(host(flag), o_flag)
+    np.testing.assert_array_equal(host(out), o_pool)
+    assert o_flag[:, -1].all() and (n < 700 or not o_flag.all())
+
+
+# ------------------------------------------------------------------------------------------------ modules, streams, graphs
+
+def _load(module, fx):
+    module.load_state_dict({k[4:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("sd__")})
+    return module.to(DEV).eval()
+
+
+def test_sa_and_fp_modules_on_gpu():
+    from epnet_amd import pointnet2_modules as p2m
+    fx = golden("sa_module.npz")
+    sa = _load(p2m.PointnetSAModuleMSG(npoint=256, radii=[0.5, 1.0], nsamples=[16, 32], mlps=[[16, 16, 32], [16, 16, 32]]), fx)
+    with torch.no_grad():
+        new_xyz, feats, idx = sa(dev(fx["xyz"]), dev(fx["features"]))
+    np.testing.assert_array_equal(host(idx), fx["idx"])
+    np.testing.assert_array_equal(host(new_xyz), fx["new_xyz"])
+    np.testing.assert_allclose(host(feats), fx["out_features"], rtol=0, atol=1e-5)
+    fp = golden("fp_module.npz")
+    fpm = _load(p2m.PointnetFPModule(mlp=[48, 32]), fp)
+    with torch.no_grad():
+        out = fpm(dev(fp["unknown"]), dev(fp["known"]), dev(fp["unknow_feats"]), dev(fp["known_feats"]))
+    np.testing.assert_allclose(host(out), fp["out"], rtol=0, atol=1e-5)
+
+
+def test_autograd_on_gpu():
+    from epnet_amd import pointnet2_utils as p2u
+    fx = golden("grads.npz")
+    feat = dev(fx["feat"]).requires_grad_(True)
+    (p2u.grouping_operation(feat, dev(fx["idx"])) * dev(fx["upstream"])).sum().backward()
+    np.testing.assert_allclose(host(feat.grad), fx["grad_feat"], rtol=1e-5, atol=1e-5)
+    kf = dev(fx["known_feats"]).requires_grad_(True)
+    (p2u.three_interpolate(kf, dev(fx["nn_idx"]), dev(fx["weight"])) * dev(fx["upstream2"])).sum().backward()
+    np.testing.assert_allclose(host(kf.grad), fx["grad_known"], rtol=1e-5, atol=1e-5)
+
+
+def test_ops_follow_the_current_stream_and_graph_replay(oracle):
+    from epnet_amd import pointnet2_utils as p2u, sa_stack, synth
+    xyz_h = synth.scenes("kitti", 2, 4096, seed=21)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        xyz = xyz_h.to(DEV, non_blocking=False)
+        idx = p2u.furthest_point_sample(xyz, 512)
+    side.synchronize()
+    np.testing.assert_array_equal(host(idx), oracle.furthest_point_sampling(xyz_h.numpy(), 512))
+
+    stack = sa_stack.SAStack(2, n=4096, device=DEV, npoints=(1024, 256, 64, 16), with_fp=False)
+    stack.run(xyz)
+    torch.cuda.synchronize()
+    eager = [host(L["fps_idx"]).copy() for L in stack.levels] + [host(S["idx"]).copy() for L in stack.levels for S in L["scales"]]
+    feats = [host(S["grouped_feat"]).copy() for L in stack.levels for S in L["scales"] if S["grouped_feat"] is not None]
+    stack.capture(xyz)
+    for L in stack.levels:
+        L["fps_idx"].zero_()
+    stack.replay()
+    torch.cuda.synchronize()
+    again = [host(L["fps_idx"]) for L in stack.levels] + [host(S["idx"]) for L in stack.levels for S in L["scales"]]
+    for a, b in zip(eager, again):
+        np.testing.assert_array_equal(a, b)
+    for a, b in zip(feats, [host(S["grouped_feat"]) for L in stack.levels for S in L["scales"] if S["grouped_feat"] is not None]):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(eager[0], oracle.furthest_point_sampling(xyz_h.numpy(), 1024))
