@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libepnet_hip.so")
+# EPNET_HIP_LIB lets kernel experiments load an alternative build; the default is the in-tree library
+LIB_PATH = os.environ.get("EPNET_HIP_LIB") or os.path.join(_HERE, "lib", "libepnet_hip.so")
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int

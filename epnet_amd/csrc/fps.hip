@@ -1,26 +1,34 @@
 // fps.hip -- furthest point sampling for gfx950.
 //
 // Replaces furthest_point_sampling_kernel / _launcher of the reference
-// (pointnet2_lib/pointnet2/src/sampling_gpu.cu:94-253). One workgroup per scene, as there, but:
+// (pointnet2_lib/pointnet2/src/sampling_gpu.cu:94-253). One workgroup per scene, as there, but the
+// M-1 dependent arg-max iterations are rebuilt around the CDNA4 execution model:
 //
 //   * the scene lives in VGPRs for the whole kernel (x, y, z and the running min distance of up
-//     to 16 points per thread) -- the reference re-reads xyz and temp from memory on each of the
-//     M-1 dependent iterations; here HBM sees N*12 B once and M*4 B of indices;
-//   * the arg-max is a wave-level butterfly on a 64-bit key followed by ONE barrier per
-//     iteration (double-buffered 16-entry LDS exchange) instead of an 11-barrier shared-memory
-//     tree;
-//   * tie-breaking is made independent of the reduction order. The reference's result depends on
-//     its block size bs = opt_n_threads(N) (cuda_utils.h:10-14): thread tid scans k = tid,
-//     tid+bs, ... keeping the FIRST maximum (strict '>', :136-137), and at every level of the
-//     tree the LOWER slot wins a tie (:86-91), i.e. among equal distances the winner is the one
-//     with the smallest (bitreverse(k mod bs), k div bs). Squared distances are >= +0, so their
-//     IEEE bit patterns order like the floats; the key
-//         (bits(d2) << 32) | (0x7fffffff - ((bitrev(k mod bs) << 20) | (k div bs)))
-//     therefore has a unique maximum, which is exactly the reference's winner.
+//     to 16 points per thread): HBM sees N*12 B once and M*4 B of indices; the reference re-reads
+//     xyz and temp from memory in every iteration;
+//   * NO global memory access inside the loop: the coordinates of each wave's candidate travel
+//     with its maximum through a 16-entry LDS exchange, and the selected indices are buffered in
+//     LDS and flushed with coalesced stores -- so the single barrier per iteration never waits on
+//     vmcnt (the reference has 11 barriers and a dependent global load per iteration);
+//   * wave-level arg-max = one DPP max-reduction of the float + __ballot + s_ff1 (no LDS
+//     butterfly), because tie-breaking is folded into the lane layout, see below.
+//
+// Tie-breaking. The reference's result depends on its block size bs = opt_n_threads(N)
+// (cuda_utils.h:10-14): thread tid scans k = tid, tid+bs, ... keeping the FIRST maximum (strict
+// '>', :136-137), and at every level of the shared-memory tree the LOWER slot wins a tie (:86-91).
+// Among equal distances the winner is therefore the point with the smallest
+//         rank(k) = (bitreverse_{log2 bs}(k mod bs), k div bs)      (lexicographic).
+// Physical thread q of this kernel holds the reference thread tid = bitreverse(q), slot j holds
+// k = tid + j*bs, so rank order == (q, j) order == (wave, lane, slot) order: the winner among tied
+// lanes is the lowest set bit of a ballot, among tied waves the lowest wave, among tied slots the
+// lowest slot. Squared distances are >= +0 and never NaN for finite inputs, so comparing their
+// bit patterns for equality is comparing the floats.
 //
 // Arithmetic: d = dx*dx + dy*dy + dz*dz evaluated left to right in fp32 without contraction
-// (the file is compiled with -ffp-contract=off), min with the running distance, as :133-135.
+// (-ffp-contract=off), then min with the running distance, as sampling_gpu.cu:133-135.
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -29,6 +37,210 @@ namespace epnet {
 __device__ __forceinline__ unsigned bitrev_lg(unsigned v, int lg) {
     return lg == 0 ? 0u : (__brev(v) >> (32 - lg));
 }
+
+// ---- DPP helpers -------------------------------------------------------------------------------
+// Distances are handled as their int32 bit patterns: for non-negative floats (and the -1.0f padding
+// value, which is a negative int) signed integer order == float order and bit equality == float
+// equality, and v_min_i32 / v_max3_i32 need none of the NaN-canonicalising v_max the compiler has to
+// put in front of every fminf / fmaxf.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+
+// max over each row of 16 lanes, result in every lane of the row
+__device__ __forceinline__ int row16_max(int v) {
+    v = max(v, dpp_i32<0xB1>(v));   // quad_perm [1,0,3,2]
+    v = max(v, dpp_i32<0x4E>(v));   // quad_perm [2,3,0,1]
+    v = max(v, dpp_i32<0x124>(v));  // row_ror:4
+    v = max(v, dpp_i32<0x128>(v));  // row_ror:8
+    return v;
+}
+
+// wave-wide max, returned wave-uniform (scalar registers)
+__device__ __forceinline__ int wave_max_i32(int v) {
+    const int r = row16_max(v);
+    const int a = __builtin_amdgcn_readlane(r, 0), b = __builtin_amdgcn_readlane(r, 16);
+    const int c = __builtin_amdgcn_readlane(r, 32), d = __builtin_amdgcn_readlane(r, 48);
+    return max(max(a, b), max(c, d));
+}
+
+constexpr int kIdxBuf = 4096;  // selected (thread, slot) codes buffered in LDS between flushes
+
+// (thread q, slot s) -> point index. Thread q owns R = bs/T consecutive rank positions r = q*R + s/J
+// (reference thread tid = bitreverse(r)) and, of each, the J = ceil(n/bs) points k = tid + j*bs.
+__device__ __forceinline__ int fps_point_of(int q, int slot, int R, int J, int lg_bs) {
+    const int r = q * R + slot / J;
+    return (int)bitrev_lg((unsigned)r, lg_bs) + (slot % J) * (1 << lg_bs);
+}
+
+// first slot (lowest index) of lane `wl` whose distance equals `target`, and that point's coordinates
+// -- all wave-uniform. Two-level search over groups of 4 slots for PPT >= 8.
+template <int PPT>
+__device__ __forceinline__ void find_slot(const int (&t)[PPT], const float (&x)[PPT], const float (&y)[PPT],
+                                          const float (&z)[PPT], const int (&g)[(PPT + 3) / 4], int wl, int target,
+                                          int &slot, float &sx, float &sy, float &sz) {
+    slot = 0;
+    sx = sy = sz = 0.f;
+    if constexpr (PPT >= 8) {
+        constexpr int NG = PPT / 4;
+        int grp = 0;
+#pragma unroll
+        for (int gi = NG - 1; gi >= 0; --gi)
+            if (__builtin_amdgcn_readlane(g[gi], wl) == target) grp = gi;  // wave-uniform
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi)
+            if (grp == gi) {
+#pragma unroll
+                for (int j = 4 * gi + 3; j >= 4 * gi; --j)
+                    if (__builtin_amdgcn_readlane(t[j], wl) == target) slot = j;
+            }
+#pragma unroll
+        for (int j = 0; j < PPT; ++j)
+            if (slot == j) {
+                sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[j]), wl));
+                sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y[j]), wl));
+                sz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z[j]), wl));
+            }
+    } else {
+#pragma unroll
+        for (int j = PPT - 1; j >= 0; --j)
+            if (__builtin_amdgcn_readlane(t[j], wl) == target) {
+                slot = j;
+                sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[j]), wl));
+                sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y[j]), wl));
+                sz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z[j]), wl));
+            }
+    }
+}
+
+// Register-resident kernel: W waves per scene, PPT point slots per thread. 64*W <= bs = 2^lg_bs,
+// R = bs / (64*W), J = ceil(n / bs), R*J <= PPT.
+template <int W, int PPT>
+__global__ __launch_bounds__(64 * W) void fps_wave_kernel(int n, int m, int lg_bs, const float *__restrict__ xyz,
+                                                          float *__restrict__ temp, int *__restrict__ idxs) {
+    __shared__ int s_val[2][16];     // per-wave maximum (bit pattern)
+    __shared__ float4 s_rec[2][16];  // per-wave candidate: x, y, z, (q << 8 | slot) as int bits
+    __shared__ int s_idx[kIdxBuf];
+    constexpr int T = 64 * W;
+    const int q = threadIdx.x;
+    const int lane = q & 63, wave = q >> 6;
+    const int bs = 1 << lg_bs;
+    const int R = bs / T, J = (n + bs - 1) / bs;
+    const int used = R * J;
+    xyz += (size_t)blockIdx.x * n * 3;
+    if (temp) temp += (size_t)blockIdx.x * n;
+    idxs += (size_t)blockIdx.x * m;
+    const int kNeg1 = __float_as_int(-1.f);
+
+    float x[PPT], y[PPT], z[PPT];
+    int t[PPT];  // running min squared distance, as bits
+#pragma unroll
+    for (int s = 0; s < PPT; ++s) {
+        const int k = s < used ? fps_point_of(q, s, R, J, lg_bs) : n;
+        if (k < n) {
+            x[s] = xyz[k * 3 + 0];
+            y[s] = xyz[k * 3 + 1];
+            z[s] = xyz[k * 3 + 2];
+            t[s] = __float_as_int(temp ? temp[k] : 1e10f);
+        } else {  // padding slot: distance pinned at -1, never a maximum (slot 0 of every thread is real)
+            x[s] = y[s] = z[s] = 0.f;
+            t[s] = kNeg1;
+        }
+    }
+    if (W > 1 && q < 32) s_val[q >> 4][q & 15] = kNeg1;
+    if (q == 0) s_idx[0] = 0;  // code of (thread 0, slot 0) == point 0
+    float x1 = xyz[0], y1 = xyz[1], z1 = xyz[2];
+    __syncthreads();
+
+    for (int it = 1; it < m; ++it) {
+        int g[(PPT + 3) / 4];
+        int best = kNeg1;
+        if constexpr (PPT >= 8) {
+#pragma unroll
+            for (int gi = 0; gi < PPT / 4; ++gi) {
+                int gm = kNeg1;
+#pragma unroll
+                for (int j = 4 * gi; j < 4 * gi + 4; ++j) {
+                    const float dx = x[j] - x1, dy = y[j] - y1, dz = z[j] - z1;
+                    const float d = dx * dx + dy * dy + dz * dz;
+                    t[j] = min(__float_as_int(d), t[j]);  // == fminf(d, temp[k]) for d >= 0 (padding: -1 stays)
+                    gm = max(gm, t[j]);
+                }
+                g[gi] = gm;
+                best = max(best, gm);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) {
+                const float dx = x[j] - x1, dy = y[j] - y1, dz = z[j] - z1;
+                const float d = dx * dx + dy * dy + dz * dz;
+                t[j] = min(__float_as_int(d), t[j]);
+                best = max(best, t[j]);
+            }
+            g[0] = best;
+        }
+        // wave arg-max: value by DPP, owner = lowest tied lane, slot = lowest tied slot of that lane
+        const int wbest = wave_max_i32(best);
+        const unsigned long long tied = __ballot(best == wbest);
+        const int wl = (int)__builtin_ctzll(tied);
+        int slot;
+        float sx, sy, sz;
+        find_slot<PPT>(t, x, y, z, g, wl, wbest, slot, sx, sy, sz);
+        const int code = ((wave * 64 + wl) << 8) | slot;
+        if constexpr (W == 1) {
+            x1 = sx;
+            y1 = sy;
+            z1 = sz;
+            s_idx[it & (kIdxBuf - 1)] = code;  // all 64 lanes, same word
+        } else {
+            const int buf = it & 1;
+            if (lane == 0) {
+                s_val[buf][wave] = wbest;
+                s_rec[buf][wave] = make_float4(sx, sy, sz, __int_as_float(code));
+            }
+            __syncthreads();  // no global traffic is in flight here: this waits on LDS only
+            // one LDS round trip: lane l < 16 fetches wave l's maximum AND record; the winner's record is
+            // then picked out of the registers with readlane
+            const int wv = s_val[buf][lane & 15];
+            const float4 rec = s_rec[buf][lane & 15];
+            const int bm = row16_max(wv);
+            const unsigned long long wtied = __ballot(wv == bm) & 0xFFFFull;
+            const int ww = (int)__builtin_ctzll(wtied);  // lowest tied wave
+            x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rec.x), ww));
+            y1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rec.y), ww));
+            z1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rec.z), ww));
+            // every lane of wave 0 stores the (uniform) winner code: a store guarded by `q == 0` would let
+            // the compiler sink the LDS load feeding the readlane into a single-lane region, where the
+            // lane being read has not loaded anything
+            const int wcode = __builtin_amdgcn_readlane(__float_as_int(rec.w), ww);
+            if (wave == 0) s_idx[it & (kIdxBuf - 1)] = wcode;
+        }
+        if ((it & (kIdxBuf - 1)) == kIdxBuf - 1 && wave == 0) {  // buffer full: wave 0 (the writer) flushes it
+            const int base = it - (kIdxBuf - 1);
+            for (int e = lane; e < kIdxBuf; e += 64) {
+                const int c = s_idx[e];
+                idxs[base + e] = fps_point_of(c >> 8, c & 0xFF, R, J, lg_bs);
+            }
+        }
+    }
+    if (wave == 0) {
+        const int base = (m - 1) & ~(kIdxBuf - 1);
+        for (int e = lane; base + e < m; e += 64) {
+            const int c = s_idx[e];
+            idxs[base + e] = fps_point_of(c >> 8, c & 0xFF, R, J, lg_bs);
+        }
+    }
+    if (temp) {
+#pragma unroll
+        for (int s = 0; s < PPT; ++s) {
+            const int k = s < used ? fps_point_of(q, s, R, J, lg_bs) : n;
+            if (k < n) temp[k] = __int_as_float(t[s]);
+        }
+    }
+}
+
+// ---- generic paths (tiny clouds with a reference block < one wave; clouds beyond the register file)
 
 __device__ __forceinline__ unsigned fps_rank(int k, int lg) {
     return (bitrev_lg((unsigned)k & ((1u << lg) - 1u), lg) << 20) | ((unsigned)k >> lg);
@@ -47,80 +259,9 @@ __device__ __forceinline__ long long wave_max_i64(long long v) {
     return v;
 }
 
-// Register-resident kernel: blockDim.x * PPT >= n, blockDim.x a multiple of the reference block
-// size 2^lg_bs (so every point held by one thread shares k mod bs and slot order == rank order).
-template <int PPT>
-__global__ __launch_bounds__(1024) void fps_reg_kernel(int n, int m, int lg_bs, const float *__restrict__ xyz,
-                                                       float *__restrict__ temp, int *__restrict__ idxs) {
-    __shared__ long long red[2][16];
-    const int BS = blockDim.x;
-    const int q = threadIdx.x;
-    const int lane = q & 63, wave = q >> 6;
-    xyz += (size_t)blockIdx.x * n * 3;
-    if (temp) temp += (size_t)blockIdx.x * n;
-    idxs += (size_t)blockIdx.x * m;
-
-    float x[PPT], y[PPT], z[PPT], t[PPT];
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-        const int k = q + j * BS;
-        if (k < n) {
-            x[j] = xyz[k * 3 + 0];
-            y[j] = xyz[k * 3 + 1];
-            z[j] = xyz[k * 3 + 2];
-            t[j] = temp ? temp[k] : 1e10f;
-        } else {  // padding slot: distance pinned at -1, can never be a maximum
-            x[j] = y[j] = z[j] = 0.f;
-            t[j] = -1.f;
-        }
-    }
-    if (q < 32) red[q >> 4][q & 15] = (long long)0x8000000000000000ull;
-    if (q == 0) idxs[0] = 0;
-    float x1 = xyz[0], y1 = xyz[1], z1 = xyz[2];
-    __syncthreads();
-
-    for (int it = 1; it < m; ++it) {
-        float best = -1.f;
-#pragma unroll
-        for (int j = 0; j < PPT; ++j) {
-            const float dx = x[j] - x1, dy = y[j] - y1, dz = z[j] - z1;
-            const float d = dx * dx + dy * dy + dz * dz;
-            t[j] = fminf(d, t[j]);
-            best = fmaxf(best, t[j]);
-        }
-        int bj = PPT - 1;  // first slot holding the thread maximum
-#pragma unroll
-        for (int j = PPT - 2; j >= 0; --j) bj = (t[j] == best) ? j : bj;
-        const unsigned rank = fps_rank(q + bj * BS, lg_bs);
-        long long key = ((long long)__float_as_int(best) << 32) | (long long)(0x7FFFFFFFu - rank);
-        key = wave_max_i64(key);
-        if (lane == 0) red[it & 1][wave] = key;
-        __syncthreads();
-        long long kk = red[it & 1][lane & 15];
-#pragma unroll
-        for (int off = 8; off >= 1; off >>= 1) {
-            const long long o = __shfl_xor(kk, off, 64);
-            kk = o > kk ? o : kk;
-        }
-        const unsigned wr = 0x7FFFFFFFu - (unsigned)(kk & 0xFFFFFFFFll);
-        const int old = __builtin_amdgcn_readfirstlane(fps_unrank(wr, lg_bs));
-        x1 = xyz[old * 3 + 0];
-        y1 = xyz[old * 3 + 1];
-        z1 = xyz[old * 3 + 2];
-        if (q == 0) idxs[it] = old;
-    }
-
-    if (temp) {
-#pragma unroll
-        for (int j = 0; j < PPT; ++j) {
-            const int k = q + j * BS;
-            if (k < n) temp[k] = t[j];
-        }
-    }
-}
-
-// Streaming kernel for scenes too large for the register file (n > 16 * 1024): xyz and temp are
-// re-read through L2 each iteration, blockDim.x == the reference block size.
+// xyz and temp re-read through L2 each iteration; arg-max on the 64-bit key
+// (bits(d2) << 32) | (0x7fffffff - rank(k)), whose unique maximum is the reference's winner.
+// blockDim.x is a multiple of the reference block size 2^lg_bs, so a thread's points share k mod bs.
 __global__ __launch_bounds__(1024) void fps_stream_kernel(int n, int m, int lg_bs, const float *__restrict__ xyz,
                                                           float *__restrict__ temp, int *__restrict__ idxs) {
     __shared__ long long red[2][16];
@@ -145,6 +286,7 @@ __global__ __launch_bounds__(1024) void fps_stream_kernel(int n, int m, int lg_b
             bestk = d2 > best ? k : bestk;
             best = d2 > best ? d2 : best;
         }
+        // threads beyond n own no point: best = -1 sorts below every real distance (signed high word)
         const unsigned rank = fps_rank(bestk, lg_bs);
         long long key = ((long long)__float_as_int(best) << 32) | (long long)(0x7FFFFFFFu - rank);
         key = wave_max_i64(key);
@@ -183,26 +325,51 @@ extern "C" int epnet_furthest_point_sampling(int b, int n, int m, const float *x
     EPNET_REQUIRE(b >= 0 && n >= 1 && m >= 0);
     if (b == 0 || m == 0) return EPNET_OK;  // the reference kernel returns at once for m <= 0
     EPNET_REQUIRE(xyz && idx);
-    if ((long long)n > (1ll << 20) * 1024) return EPNET_ELIMIT;  // rank field is 20 bits of k div bs
+    if ((long long)n > (1ll << 20) * 1024) return EPNET_ELIMIT;  // rank field: 20 bits of k div bs
     hipStream_t s = (hipStream_t)stream;
     const int lg = ref_block_lg(n);
     const int bs_ref = 1 << lg;
-    const int bs = bs_ref < 64 ? 64 : bs_ref;  // physical block: at least one wave
-    const int ppt = div_up(n, bs);
-    dim3 grid(b), block(bs);
-    if (ppt <= 1)
-        hipLaunchKernelGGL(fps_reg_kernel<1>, grid, block, 0, s, n, m, lg, xyz, temp, idx);
-    else if (ppt <= 2)
-        hipLaunchKernelGGL(fps_reg_kernel<2>, grid, block, 0, s, n, m, lg, xyz, temp, idx);
-    else if (ppt <= 4)
-        hipLaunchKernelGGL(fps_reg_kernel<4>, grid, block, 0, s, n, m, lg, xyz, temp, idx);
-    else if (ppt <= 8)
-        hipLaunchKernelGGL(fps_reg_kernel<8>, grid, block, 0, s, n, m, lg, xyz, temp, idx);
-    else if (ppt <= 16)
-        hipLaunchKernelGGL(fps_reg_kernel<16>, grid, block, 0, s, n, m, lg, xyz, temp, idx);
-    else {
-        EPNET_REQUIRE(temp != nullptr);  // the streaming path keeps the distances in the caller's buffer
-        hipLaunchKernelGGL(fps_stream_kernel, grid, block, 0, s, n, m, lg, xyz, temp, idx);
+    dim3 grid(b);
+    const int J = div_up(n, bs_ref);
+    if (bs_ref >= 64 && J <= 16) {
+        // fewest waves whose threads can hold the scene in <= 16 slots each (fewer waves = cheaper
+        // cross-wave exchange and more scenes per CU); EPNET_FPS_WAVES overrides for tuning
+        int waves = bs_ref / 64;
+        for (int w = 1; w <= bs_ref / 64; w *= 2)
+            if ((bs_ref / (64 * w)) * J <= 16) {
+                waves = w;
+                break;
+            }
+        if (const char *e = getenv("EPNET_FPS_WAVES")) {
+            const int w = atoi(e);
+            if (w >= 1 && w <= bs_ref / 64 && (w & (w - 1)) == 0 && (bs_ref / (64 * w)) * J <= 16) waves = w;
+        }
+        const int ppt = (bs_ref / (64 * waves)) * J;
+#define EPNET_FPS_LAUNCH(W_, P_) \
+    hipLaunchKernelGGL((fps_wave_kernel<W_, P_>), grid, dim3(64 * W_), 0, s, n, m, lg, xyz, temp, idx)
+#define EPNET_FPS_PPT(W_)                      \
+    do {                                       \
+        if (ppt <= 1) EPNET_FPS_LAUNCH(W_, 1); \
+        else if (ppt <= 2) EPNET_FPS_LAUNCH(W_, 2); \
+        else if (ppt <= 4) EPNET_FPS_LAUNCH(W_, 4); \
+        else if (ppt <= 8) EPNET_FPS_LAUNCH(W_, 8); \
+        else EPNET_FPS_LAUNCH(W_, 16);         \
+    } while (0)
+        switch (waves) {
+            case 1: EPNET_FPS_PPT(1); break;
+            case 2: EPNET_FPS_PPT(2); break;
+            case 4: EPNET_FPS_PPT(4); break;
+            case 8: EPNET_FPS_PPT(8); break;
+            default: EPNET_FPS_PPT(16); break;
+        }
+#undef EPNET_FPS_PPT
+#undef EPNET_FPS_LAUNCH
+        return check_launch("furthest_point_sampling");
     }
+    // generic path: needs the running distances in memory
+    float *tbuf = temp;
+    if (!tbuf) return EPNET_EINVAL;  // temp may only be NULL on the register-resident path
+    const int bs = bs_ref < 64 ? 64 : bs_ref;
+    hipLaunchKernelGGL(fps_stream_kernel, grid, dim3(bs), 0, s, n, m, lg, xyz, tbuf, idx);
     return check_launch("furthest_point_sampling");
 }
