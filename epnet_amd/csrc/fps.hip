@@ -32,7 +32,14 @@
 
 #include "common.h"
 
+// clang exposes no builtin for v_writelane_b32; bind the LLVM intrinsic by name (value, lane, old)
+extern "C" __device__ int epnet_llvm_writelane_i32(int, int, int) __asm("llvm.amdgcn.writelane.i32");
+
 namespace epnet {
+
+__device__ __forceinline__ int writelane_i32(int value, int lane, int old) {
+    return epnet_llvm_writelane_i32(value, lane, old);
+}
 
 __device__ __forceinline__ unsigned bitrev_lg(unsigned v, int lg) {
     return lg == 0 ? 0u : (__brev(v) >> (32 - lg));
@@ -240,6 +247,327 @@ __global__ __launch_bounds__(64 * W) void fps_wave_kernel(int n, int m, int lg_b
     }
 }
 
+// ---- pruned kernel ------------------------------------------------------------------------------
+//
+// Exact FPS with spatial pruning, for 1024 < N <= 16384. The points are sorted along a Morton curve
+// (in-kernel bitonic sort in LDS) and dealt to "buckets" of 64 consecutive sorted points: bucket b is
+// slot b/W of wave b%W, one point per lane. A wave keeps, for each of its buckets j, a summary in LANE j
+// of a few registers (bounding box, maximum running distance bm, reference rank of the point holding
+// it) plus that point's coordinates in a small LDS table. A new sample c can only lower distances in
+// buckets whose box lies closer than their bm, so per round a wave
+//   A. evaluates L_j = |clamp(c, box_j) - c|^2 for all its buckets at once (one bucket per lane),
+//   B. updates only the buckets with L_j < bm_j (typically 0-3 of them; the slot registers are
+//      addressed with the gfx9 GPR-index mode, so there is one copy of the code and no branch tree),
+//   C. reduces its bucket maxima and publishes (value, coordinates, rank) of its best point,
+//   D. after the single barrier picks the best wave's record.
+// Everything after the `active` mask stays on the vector ALU (DPP / permlane-swap reductions, lane
+// masks instead of readlane -> SALU -> VALU round trips).
+// Skipping is EXACT, not approximate: L_j is computed with the very expression used for point
+// distances (dx*dx + dy*dy + dz*dz, fp32, no contraction) on the clamped point; fp32 subtraction,
+// multiplication and addition are monotone, so every point of the bucket has d >= L_j >= bm_j >= its
+// running distance and min(d, t) = t bit for bit. Tie-breaks cannot follow the lane order here (the
+// layout is spatial): every maximum carries the reference rank of its point,
+// rank(k) = (bitreverse10(k mod 1024) << 4) | (k div 1024)  (block size 1024 for every N > 1024),
+// and equal distances are resolved by the smaller rank inside a bucket, between buckets and between
+// waves -- exactly the winner of the reference's strided scan + shared-memory tree.
+namespace pruned {
+
+#ifdef EPNET_FPS_STATS  // diagnostic build only (scratch/fps_stats.hip): phase cycle counters
+__device__ unsigned long long g_stats[16];
+#define EPNET_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define EPNET_ACC(slot, a, b) if ((threadIdx.x & 63) == 0) atomicAdd(&g_stats[slot], (unsigned long long)((b) - (a)))
+#define EPNET_CNT(slot, v) if ((threadIdx.x & 63) == 0) atomicAdd(&g_stats[slot], (unsigned long long)(v))
+#else
+#define EPNET_STAMP(var)
+#define EPNET_ACC(slot, a, b)
+#define EPNET_CNT(slot, v)
+#endif
+
+__device__ __forceinline__ unsigned spread10(unsigned v) {  // ..9876543210 -> ..9__8__7__6__5__4__3__2__1__0
+    v &= 0x3FFu;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+__device__ __forceinline__ unsigned rank14(int k) { return (bitrev_lg((unsigned)k & 1023u, 10) << 4) | ((unsigned)k >> 10); }
+__device__ __forceinline__ int unrank14(unsigned r) { return (int)(bitrev_lg(r >> 4, 10) + ((r & 15u) << 10)); }
+
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+
+// reductions whose result lands in EVERY lane (no scalar round trip)
+__device__ __forceinline__ int wave_max_all(int v) {
+    v = row16_max(v);
+    const auto a = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    v = max((int)a[0], (int)a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    return max((int)b[0], (int)b[1]);
+}
+
+__device__ __forceinline__ unsigned wave_min_all(unsigned v) {
+    v = min(v, dpp_u32<0xB1>(v));
+    v = min(v, dpp_u32<0x4E>(v));
+    v = min(v, dpp_u32<0x124>(v));
+    v = min(v, dpp_u32<0x128>(v));
+    const auto a = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    v = min(a[0], a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return min(b[0], b[1]);
+}
+
+// data replicated with period P (a power of two <= 16) along the lanes: reduce over one period
+template <int P>
+__device__ __forceinline__ int period_max(int v) {
+    if (P > 1) v = max(v, dpp_i32<0xB1>(v));
+    if (P > 2) v = max(v, dpp_i32<0x4E>(v));
+    if (P > 4) v = max(v, dpp_i32<0x124>(v));
+    if (P > 8) v = max(v, dpp_i32<0x128>(v));
+    return v;
+}
+template <int P>
+__device__ __forceinline__ unsigned period_min(unsigned v) {
+    if (P > 1) v = min(v, dpp_u32<0xB1>(v));
+    if (P > 2) v = min(v, dpp_u32<0x4E>(v));
+    if (P > 4) v = min(v, dpp_u32<0x124>(v));
+    if (P > 8) v = min(v, dpp_u32<0x128>(v));
+    return v;
+}
+
+// W waves per scene (4: one per SIMD; 8 for N > 8192), PPT buckets per wave.
+template <int kW, int PPT>
+__global__ __launch_bounds__(64 * kW) void fps_pruned_kernel(int n, int m, const float *__restrict__ xyz,
+                                                             float *__restrict__ temp, int *__restrict__ idxs) {
+    typedef float vecf __attribute__((ext_vector_type(PPT)));
+    typedef int veci __attribute__((ext_vector_type(PPT)));
+    constexpr int kT = 64 * kW;
+    constexpr int NP = kT * PPT;  // padded point count (power of two)
+    // dynamic LDS: NP 64-bit sort keys (morton << 16 | k); afterwards its head is reused for the sorted
+    // order's reference ranks, 16 bits each (0xFFFF = padding)
+    extern __shared__ unsigned long long s_sort[];
+    __shared__ float s_box[6][8];
+    __shared__ float4 s_hold[kW][PPT];  // per bucket: x, y, z of the point holding its maximum, rank bits
+    __shared__ int s_val[2][16];
+    __shared__ float4 s_rec[2][16];
+    __shared__ int s_idx[kIdxBuf];
+    const int q = threadIdx.x;
+    const int lane = q & 63, wave = q >> 6;
+    xyz += (size_t)blockIdx.x * n * 3;
+    if (temp) temp += (size_t)blockIdx.x * n;
+    idxs += (size_t)blockIdx.x * m;
+    const int kNeg1 = __float_as_int(-1.f);
+
+    // ---- scene bounding box
+    float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+    for (int k = q; k < n; k += kT)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = xyz[k * 3 + a];
+            lo[a] = fminf(lo[a], v);
+            hi[a] = fmaxf(hi[a], v);
+        }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], off, 64));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off, 64));
+        }
+        if (lane == 0) {
+            s_box[a][wave] = lo[a];
+            s_box[3 + a][wave] = hi[a];
+        }
+    }
+    __syncthreads();
+    float ext = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float l = s_box[a][0], h = s_box[3 + a][0];
+#pragma unroll
+        for (int w = 1; w < kW; ++w) {
+            l = fminf(l, s_box[a][w]);
+            h = fmaxf(h, s_box[3 + a][w]);
+        }
+        lo[a] = l;
+        ext = fmaxf(ext, h - l);
+    }
+    const float scale = ext > 0.f ? 1023.f / ext : 0.f;  // one cell size for all axes
+
+    // ---- Morton keys, bitonic sort (ascending); padding keys sort last
+    for (int k = q; k < NP; k += kT) {
+        unsigned long long key = ~0ull;
+        if (k < n) {
+            const unsigned ix = (unsigned)fminf((xyz[k * 3 + 0] - lo[0]) * scale, 1023.f);
+            const unsigned iy = (unsigned)fminf((xyz[k * 3 + 1] - lo[1]) * scale, 1023.f);
+            const unsigned iz = (unsigned)fminf((xyz[k * 3 + 2] - lo[2]) * scale, 1023.f);
+            const unsigned code = spread10(ix) | (spread10(iy) << 1) | (spread10(iz) << 2);
+            key = ((unsigned long long)code << 16) | (unsigned long long)k;
+        }
+        s_sort[k] = key;
+    }
+    __syncthreads();
+    for (int k2 = 2; k2 <= NP; k2 <<= 1)
+        for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+            for (int i = q; i < NP / 2; i += kT) {
+                const int a = ((i & ~(j2 - 1)) << 1) | (i & (j2 - 1));
+                const int b = a | j2;
+                const unsigned long long ka = s_sort[a], kb = s_sort[b];
+                const bool up = (a & k2) == 0;
+                if ((ka > kb) == up) {
+                    s_sort[a] = kb;
+                    s_sort[b] = ka;
+                }
+            }
+            __syncthreads();
+        }
+
+    // ---- sorted position p = (bucket << 6 | lane); bucket b -> (wave b % kW, slot b / kW).
+    // Pull this thread's indices out of the key array, then reuse the array's head for the rank table.
+    unsigned short *rank16 = reinterpret_cast<unsigned short *>(s_sort);
+    vecf x, y, z;
+    veci t;
+    {
+        unsigned ktmp[PPT];
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const unsigned long long key = s_sort[((j * kW + wave) << 6) | lane];
+            ktmp[j] = key == ~0ull ? 0xFFFFu : (unsigned)(key & 0xFFFFull);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            if (ktmp[j] != 0xFFFFu) {
+                const int k = (int)ktmp[j];
+                rank16[((j * kW + wave) << 6) | lane] = (unsigned short)rank14(k);
+                x[j] = xyz[k * 3 + 0];
+                y[j] = xyz[k * 3 + 1];
+                z[j] = xyz[k * 3 + 2];
+                t[j] = __float_as_int(temp ? temp[k] : 1e10f);
+            } else {  // padding: distance pinned at -1
+                rank16[((j * kW + wave) << 6) | lane] = 0xFFFFu;
+                x[j] = y[j] = z[j] = 0.f;
+                t[j] = kNeg1;
+            }
+        }
+    }
+
+    // ---- bucket summaries: lane j <-> bucket j of this wave
+    int bm = kNeg1;
+    unsigned brank = 0xFFFFu;
+    float lox = 0.f, hix = 0.f, loy = 0.f, hiy = 0.f, loz = 0.f, hiz = 0.f;
+    for (int j = 0; j < PPT; ++j) {  // runtime loop, indexed registers: one copy of the code
+        const float xj = x[j], yj = y[j], zj = z[j];
+        const int tj = t[j];
+        const unsigned rk = rank16[((j * kW + wave) << 6) | lane];
+        const bool real = rk != 0xFFFFu;
+        float mn[3] = {real ? xj : 3.4e38f, real ? yj : 3.4e38f, real ? zj : 3.4e38f};
+        float mx[3] = {real ? xj : -3.4e38f, real ? yj : -3.4e38f, real ? zj : -3.4e38f};
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                mn[a] = fminf(mn[a], __shfl_xor(mn[a], off, 64));
+                mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off, 64));
+            }
+        const int nb = wave_max_all(tj);
+        const unsigned r = (tj == nb) ? rk : 0xFFFFu;
+        const unsigned rmin = wave_min_all(r);
+        if (r == rmin && real) s_hold[wave][j] = make_float4(xj, yj, zj, __uint_as_float(rmin));
+        const bool any = __ballot(real) != 0ull;
+        if (lane == j) {
+            bm = nb;
+            brank = rmin;
+            lox = any ? mn[0] : 0.f; hix = any ? mx[0] : 0.f;
+            loy = any ? mn[1] : 0.f; hiy = any ? mx[1] : 0.f;
+            loz = any ? mn[2] : 0.f; hiz = any ? mx[2] : 0.f;
+        }
+    }
+    if (q < 32) s_val[q >> 4][q & 15] = kNeg1;
+    if (q == 0) s_idx[0] = 0;
+    float cx = xyz[0], cy = xyz[1], cz = xyz[2];
+    __syncthreads();
+
+    EPNET_STAMP(t_loop0);
+    for (int it = 1; it < m; ++it) {
+        EPNET_STAMP(t0);
+        // A. which of this wave's buckets can change? (lanes >= PPT hold bm = -1: never active, never best)
+        const float px = __builtin_amdgcn_fmed3f(cx, lox, hix), py = __builtin_amdgcn_fmed3f(cy, loy, hiy),
+                    pz = __builtin_amdgcn_fmed3f(cz, loz, hiz);
+        const float bdx = px - cx, bdy = py - cy, bdz = pz - cz;
+        const float L = bdx * bdx + bdy * bdy + bdz * bdz;
+        unsigned long long active = __ballot(__float_as_int(L) < bm);
+        EPNET_CNT(0, __popcll(active));
+        EPNET_STAMP(t1);
+        // B. update them
+        while (active) {
+            const int j = (int)__builtin_ctzll(active);
+            active &= active - 1ull;
+            const unsigned rk = rank16[((j * kW + wave) << 6) | lane];  // latency hidden behind the arithmetic
+            const float xj = x[j], yj = y[j], zj = z[j];
+            const float dx = xj - cx, dy = yj - cy, dz = zj - cz;
+            const float d = dx * dx + dy * dy + dz * dz;
+            const int tj = min(__float_as_int(d), t[j]);  // == fminf(d, temp[k]); padding stays at -1
+            t[j] = tj;
+            const int nb = wave_max_all(tj);
+            const unsigned r = (tj == nb) ? rk : 0xFFFFu;
+            const unsigned rmin = wave_min_all(r);  // equal distances: the smaller reference rank holds the bucket
+            if (r == rmin && rk != 0xFFFFu) s_hold[wave][j] = make_float4(xj, yj, zj, __uint_as_float(rmin));
+            bm = (lane == j) ? nb : bm;
+            brank = (lane == j) ? rmin : brank;
+        }
+        EPNET_STAMP(t2);
+        // C. this wave's best bucket (lane b <-> bucket b): max distance, then min rank; that lane publishes
+        const float4 mine = s_hold[wave][lane < PPT ? lane : 0];  // issued early, consumed after the reductions
+        const int wbest = wave_max_all(bm);
+        const unsigned rr = (bm == wbest) ? brank : 0xFFFFFFFFu;
+        const unsigned rrmin = wave_min_all(rr);
+        const int buf = it & 1;
+        if (rr == rrmin && lane < PPT) {  // exactly one lane: ranks are unique
+            s_val[buf][wave] = wbest;
+            s_rec[buf][wave] = mine;
+        }
+        EPNET_STAMP(t3);
+        __syncthreads();
+        EPNET_STAMP(t4);
+        // D. best wave: the records are replicated with period kW along the lanes
+        const int wv = s_val[buf][lane & (kW - 1)];
+        const float4 rec = s_rec[buf][lane & (kW - 1)];
+        const int bmx = period_max<kW>(wv);
+        const unsigned r2 = (wv == bmx) ? __float_as_uint(rec.w) : 0xFFFFFFFFu;
+        const unsigned r2min = period_min<kW>(r2);
+        // the winning record sits in lanes l with (l & (kW-1)) == its wave: spread it with a masked max
+        const bool win = r2 == r2min;
+        cx = __int_as_float(period_max<kW>(win ? __float_as_int(rec.x) : (int)0x80000000));
+        cy = __int_as_float(period_max<kW>(win ? __float_as_int(rec.y) : (int)0x80000000));
+        cz = __int_as_float(period_max<kW>(win ? __float_as_int(rec.z) : (int)0x80000000));
+        if (q == 0) s_idx[it & (kIdxBuf - 1)] = unrank14(r2min);
+        if ((it & (kIdxBuf - 1)) == kIdxBuf - 1 && wave == 0) {
+            const int base = it - (kIdxBuf - 1);
+            for (int e = lane; e < kIdxBuf; e += 64) idxs[base + e] = s_idx[e];
+        }
+        EPNET_STAMP(t5);
+        EPNET_ACC(1, t0, t1); EPNET_ACC(2, t1, t2); EPNET_ACC(3, t2, t3); EPNET_ACC(4, t3, t4); EPNET_ACC(5, t4, t5);
+    }
+    EPNET_STAMP(t_loop1);
+    EPNET_ACC(6, t_loop0, t_loop1);
+    if (wave == 0) {
+        const int base = (m - 1) & ~(kIdxBuf - 1);
+        for (int e = lane; base + e < m; e += 64) idxs[base + e] = s_idx[e];
+    }
+    if (temp) {
+        for (int j = 0; j < PPT; ++j) {
+            const unsigned rk = rank16[((j * kW + wave) << 6) | lane];
+            if (rk != 0xFFFFu) temp[unrank14(rk)] = __int_as_float(t[j]);
+        }
+    }
+}
+
+}  // namespace pruned
+
 // ---- generic paths (tiny clouds with a reference block < one wave; clouds beyond the register file)
 
 __device__ __forceinline__ unsigned fps_rank(int k, int lg) {
@@ -331,6 +659,24 @@ extern "C" int epnet_furthest_point_sampling(int b, int n, int m, const float *x
     const int bs_ref = 1 << lg;
     dim3 grid(b);
     const int J = div_up(n, bs_ref);
+    // 1024 < n <= 16384: exact spatially-pruned kernel (EPNET_FPS_PRUNE=0 forces the brute-force path)
+    static const bool prune_enabled = !(getenv("EPNET_FPS_PRUNE") && atoi(getenv("EPNET_FPS_PRUNE")) == 0);
+    static const int prune_min = getenv("EPNET_FPS_PRUNE_MIN") ? atoi(getenv("EPNET_FPS_PRUNE_MIN")) : 4096;
+    if (prune_enabled && n > 1024 && n > prune_min && n <= 16384 && m > 1) {
+        // buckets of 64 points: 4 waves x {8,16,32} slots, 8 waves x 32 slots above 8192 points
+        const int waves = n > 8192 ? 8 : 4;
+        const int ppt_need = div_up(n, 64 * waves);
+        const int ppt = ppt_need <= 8 ? 8 : ppt_need <= 16 ? 16 : 32;
+        const size_t lds = (size_t)64 * waves * ppt * sizeof(unsigned long long);
+#define EPNET_FPS_PRUNED(W_, P_) \
+    hipLaunchKernelGGL((pruned::fps_pruned_kernel<W_, P_>), grid, dim3(64 * W_), lds, s, n, m, xyz, temp, idx)
+        if (waves == 8) EPNET_FPS_PRUNED(8, 32);
+        else if (ppt == 8) EPNET_FPS_PRUNED(4, 8);
+        else if (ppt == 16) EPNET_FPS_PRUNED(4, 16);
+        else EPNET_FPS_PRUNED(4, 32);
+#undef EPNET_FPS_PRUNED
+        return check_launch("furthest_point_sampling");
+    }
     if (bs_ref >= 64 && J <= 16) {
         // fewest waves whose threads can hold the scene in <= 16 slots each (fewer waves = cheaper
         // cross-wave exchange and more scenes per CU); EPNET_FPS_WAVES overrides for tuning
