@@ -320,6 +320,34 @@ __device__ __forceinline__ unsigned wave_min_all(unsigned v) {
     return min(b[0], b[1]);
 }
 
+// max over aligned groups of G lanes (G = 8, 16 or 32), result in every lane of the group
+template <int G>
+__device__ __forceinline__ int group_max(int v) {
+    v = max(v, dpp_i32<0xB1>(v));                  // quad_perm [1,0,3,2]
+    v = max(v, dpp_i32<0x4E>(v));                  // quad_perm [2,3,0,1]
+    v = max(v, dpp_i32<0x141>(v));                 // row_half_mirror: the other quad of the 8-lane half
+    if (G >= 16) v = max(v, dpp_i32<0x140>(v));    // row_mirror: the other half of the row
+    if (G >= 32) {
+        const auto a = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+        v = max((int)a[0], (int)a[1]);
+    }
+    return v;
+}
+template <int G>
+__device__ __forceinline__ float group_minf(float v) {
+    v = fminf(v, __int_as_float(dpp_i32<0xB1>(__float_as_int(v))));
+    v = fminf(v, __int_as_float(dpp_i32<0x4E>(__float_as_int(v))));
+    v = fminf(v, __int_as_float(dpp_i32<0x141>(__float_as_int(v))));
+    if (G >= 16) v = fminf(v, __int_as_float(dpp_i32<0x140>(__float_as_int(v))));
+    if (G >= 32) {
+        const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = fminf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    }
+    return v;
+}
+template <int G>
+__device__ __forceinline__ float group_maxf(float v) { return -group_minf<G>(-v); }
+
 // data replicated with period P (a power of two <= 16) along the lanes: reduce over one period
 template <int P>
 __device__ __forceinline__ int period_max(int v) {
@@ -338,24 +366,35 @@ __device__ __forceinline__ unsigned period_min(unsigned v) {
     return v;
 }
 
-// W waves per scene (4: one per SIMD; 8 for N > 8192), PPT buckets per wave.
+// fold a 64-lane ballot over the 64/PPT parts of a slot: bit j set <=> some part of slot j is set
+template <int PPT>
+__device__ __forceinline__ unsigned fold_parts(unsigned long long a) {
+    if (PPT <= 32) a |= a >> 32;
+    if (PPT <= 16) a |= a >> 16;
+    if (PPT <= 8) a |= a >> 8;
+    return (unsigned)a & (PPT >= 32 ? 0xFFFFFFFFu : ((1u << PPT) - 1u));
+}
+
+// W waves per scene (4: one per SIMD; 8 for N > 8192), PPT slots of 64 points per wave.
+// A slot is split into 64/PPT parts of PPT lanes: these parts are the pruning buckets, and bucket
+// (slot j, part p) is summarised in lane p*PPT + j -- a lane of the part itself, so a part's maximum
+// reaches its summary lane with an in-row DPP reduction and a lane-id compare, no cross-lane move.
 template <int kW, int PPT>
 __global__ __launch_bounds__(64 * kW) void fps_pruned_kernel(int n, int m, const float *__restrict__ xyz,
                                                              float *__restrict__ temp, int *__restrict__ idxs) {
     typedef float vecf __attribute__((ext_vector_type(PPT)));
     typedef int veci __attribute__((ext_vector_type(PPT)));
+    typedef unsigned vecr __attribute__((ext_vector_type(PPT / 2)));
     constexpr int kT = 64 * kW;
     constexpr int NP = kT * PPT;  // padded point count (power of two)
-    // dynamic LDS: NP 64-bit sort keys (morton << 16 | k); afterwards its head is reused for the sorted
-    // order's reference ranks, 16 bits each (0xFFFF = padding)
-    extern __shared__ unsigned long long s_sort[];
+    extern __shared__ unsigned long long s_sort[];  // NP sort keys: (morton << 16) | k
     __shared__ float s_box[6][8];
-    __shared__ float4 s_hold[kW][PPT];  // per bucket: x, y, z of the point holding its maximum, rank bits
     __shared__ int s_val[2][16];
     __shared__ float4 s_rec[2][16];
     __shared__ int s_idx[kIdxBuf];
     const int q = threadIdx.x;
     const int lane = q & 63, wave = q >> 6;
+    const int sub = lane & (PPT - 1);  // the slot this lane summarises (for its own part)
     xyz += (size_t)blockIdx.x * n * 3;
     if (temp) temp += (size_t)blockIdx.x * n;
     idxs += (size_t)blockIdx.x * m;
@@ -425,65 +464,46 @@ __global__ __launch_bounds__(64 * kW) void fps_pruned_kernel(int n, int m, const
             __syncthreads();
         }
 
-    // ---- sorted position p = (bucket << 6 | lane); bucket b -> (wave b % kW, slot b / kW).
-    // Pull this thread's indices out of the key array, then reuse the array's head for the rank table.
-    unsigned short *rank16 = reinterpret_cast<unsigned short *>(s_sort);
+    // ---- sorted position p = (group << 6 | lane); group g of 64 sorted points -> (wave g % kW, slot g / kW)
     vecf x, y, z;
     veci t;
-    {
-        unsigned ktmp[PPT];
+    vecr rk2;  // reference ranks of this thread's points, two 16-bit values per register (0xFFFF = padding)
 #pragma unroll
-        for (int j = 0; j < PPT; ++j) {
-            const unsigned long long key = s_sort[((j * kW + wave) << 6) | lane];
-            ktmp[j] = key == ~0ull ? 0xFFFFu : (unsigned)(key & 0xFFFFull);
+    for (int j = 0; j < PPT; ++j) {
+        const unsigned long long key = s_sort[((j * kW + wave) << 6) | lane];
+        unsigned r16 = 0xFFFFu;
+        if (key != ~0ull) {
+            const int k = (int)(key & 0xFFFFull);
+            r16 = rank14(k);
+            x[j] = xyz[k * 3 + 0];
+            y[j] = xyz[k * 3 + 1];
+            z[j] = xyz[k * 3 + 2];
+            t[j] = __float_as_int(temp ? temp[k] : 1e10f);
+        } else {  // padding: distance pinned at -1
+            x[j] = y[j] = z[j] = 0.f;
+            t[j] = kNeg1;
         }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < PPT; ++j) {
-            if (ktmp[j] != 0xFFFFu) {
-                const int k = (int)ktmp[j];
-                rank16[((j * kW + wave) << 6) | lane] = (unsigned short)rank14(k);
-                x[j] = xyz[k * 3 + 0];
-                y[j] = xyz[k * 3 + 1];
-                z[j] = xyz[k * 3 + 2];
-                t[j] = __float_as_int(temp ? temp[k] : 1e10f);
-            } else {  // padding: distance pinned at -1
-                rank16[((j * kW + wave) << 6) | lane] = 0xFFFFu;
-                x[j] = y[j] = z[j] = 0.f;
-                t[j] = kNeg1;
-            }
-        }
+        if (j & 1) rk2[j >> 1] |= r16 << 16;
+        else rk2[j >> 1] = r16;
     }
 
-    // ---- bucket summaries: lane j <-> bucket j of this wave
+    // ---- bucket summaries
     int bm = kNeg1;
-    unsigned brank = 0xFFFFu;
     float lox = 0.f, hix = 0.f, loy = 0.f, hiy = 0.f, loz = 0.f, hiz = 0.f;
     for (int j = 0; j < PPT; ++j) {  // runtime loop, indexed registers: one copy of the code
         const float xj = x[j], yj = y[j], zj = z[j];
         const int tj = t[j];
-        const unsigned rk = rank16[((j * kW + wave) << 6) | lane];
-        const bool real = rk != 0xFFFFu;
-        float mn[3] = {real ? xj : 3.4e38f, real ? yj : 3.4e38f, real ? zj : 3.4e38f};
-        float mx[3] = {real ? xj : -3.4e38f, real ? yj : -3.4e38f, real ? zj : -3.4e38f};
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                mn[a] = fminf(mn[a], __shfl_xor(mn[a], off, 64));
-                mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off, 64));
-            }
-        const int nb = wave_max_all(tj);
-        const unsigned r = (tj == nb) ? rk : 0xFFFFu;
-        const unsigned rmin = wave_min_all(r);
-        if (r == rmin && real) s_hold[wave][j] = make_float4(xj, yj, zj, __uint_as_float(rmin));
-        const bool any = __ballot(real) != 0ull;
-        if (lane == j) {
-            bm = nb;
-            brank = rmin;
-            lox = any ? mn[0] : 0.f; hix = any ? mx[0] : 0.f;
-            loy = any ? mn[1] : 0.f; hiy = any ? mx[1] : 0.f;
-            loz = any ? mn[2] : 0.f; hiz = any ? mx[2] : 0.f;
+        const bool real = tj != kNeg1;
+        const float mnx = group_minf<PPT>(real ? xj : 3.4e38f), mxx = group_maxf<PPT>(real ? xj : -3.4e38f);
+        const float mny = group_minf<PPT>(real ? yj : 3.4e38f), mxy = group_maxf<PPT>(real ? yj : -3.4e38f);
+        const float mnz = group_minf<PPT>(real ? zj : 3.4e38f), mxz = group_maxf<PPT>(real ? zj : -3.4e38f);
+        const int gm = group_max<PPT>(tj);  // -1 for an all-padding bucket: never active, never best
+        if (sub == j) {
+            const bool any = gm != kNeg1;
+            bm = gm;
+            lox = any ? mnx : 0.f; hix = any ? mxx : 0.f;
+            loy = any ? mny : 0.f; hiy = any ? mxy : 0.f;
+            loz = any ? mnz : 0.f; hiz = any ? mxz : 0.f;
         }
     }
     if (q < 32) s_val[q >> 4][q & 15] = kNeg1;
@@ -494,41 +514,47 @@ __global__ __launch_bounds__(64 * kW) void fps_pruned_kernel(int n, int m, const
     EPNET_STAMP(t_loop0);
     for (int it = 1; it < m; ++it) {
         EPNET_STAMP(t0);
-        // A. which of this wave's buckets can change? (lanes >= PPT hold bm = -1: never active, never best)
+        // A. which buckets can change?
         const float px = __builtin_amdgcn_fmed3f(cx, lox, hix), py = __builtin_amdgcn_fmed3f(cy, loy, hiy),
                     pz = __builtin_amdgcn_fmed3f(cz, loz, hiz);
         const float bdx = px - cx, bdy = py - cy, bdz = pz - cz;
         const float L = bdx * bdx + bdy * bdy + bdz * bdz;
-        unsigned long long active = __ballot(__float_as_int(L) < bm);
-        EPNET_CNT(0, __popcll(active));
+        unsigned active = fold_parts<PPT>(__ballot(__float_as_int(L) < bm));
+        EPNET_CNT(0, __popc(active));
         EPNET_STAMP(t1);
-        // B. update them
+        // B. update the slots that contain one
         while (active) {
-            const int j = (int)__builtin_ctzll(active);
-            active &= active - 1ull;
-            const unsigned rk = rank16[((j * kW + wave) << 6) | lane];  // latency hidden behind the arithmetic
-            const float xj = x[j], yj = y[j], zj = z[j];
-            const float dx = xj - cx, dy = yj - cy, dz = zj - cz;
+            const int j = (int)__builtin_ctz(active);
+            active &= active - 1u;
+            const float dx = x[j] - cx, dy = y[j] - cy, dz = z[j] - cz;
             const float d = dx * dx + dy * dy + dz * dz;
             const int tj = min(__float_as_int(d), t[j]);  // == fminf(d, temp[k]); padding stays at -1
             t[j] = tj;
-            const int nb = wave_max_all(tj);
-            const unsigned r = (tj == nb) ? rk : 0xFFFFu;
-            const unsigned rmin = wave_min_all(r);  // equal distances: the smaller reference rank holds the bucket
-            if (r == rmin && rk != 0xFFFFu) s_hold[wave][j] = make_float4(xj, yj, zj, __uint_as_float(rmin));
-            bm = (lane == j) ? nb : bm;
-            brank = (lane == j) ? rmin : brank;
+            const int gm = group_max<PPT>(tj);
+            bm = (sub == j) ? gm : bm;
         }
         EPNET_STAMP(t2);
-        // C. this wave's best bucket (lane b <-> bucket b): max distance, then min rank; that lane publishes
-        const float4 mine = s_hold[wave][lane < PPT ? lane : 0];  // issued early, consumed after the reductions
+        // C. this wave's maximum; the points that hold it (usually one) compete by reference rank
         const int wbest = wave_max_all(bm);
-        const unsigned rr = (bm == wbest) ? brank : 0xFFFFFFFFu;
-        const unsigned rrmin = wave_min_all(rr);
+        unsigned cand = fold_parts<PPT>(__ballot(bm == wbest));
+        unsigned racc = 0xFFFFFFFFu;
+        float xa = 0.f, ya = 0.f, za = 0.f;
+        do {
+            const int j = (int)__builtin_ctz(cand);
+            cand &= cand - 1u;
+            const unsigned rk = (rk2[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+            const unsigned r = (t[j] == wbest) ? rk : 0xFFFFFFFFu;
+            const bool take = r < racc;
+            racc = take ? r : racc;
+            xa = take ? x[j] : xa;
+            ya = take ? y[j] : ya;
+            za = take ? z[j] : za;
+        } while (cand);
+        const unsigned rmin = wave_min_all(racc);
         const int buf = it & 1;
-        if (rr == rrmin && lane < PPT) {  // exactly one lane: ranks are unique
+        if (racc == rmin) {  // exactly one lane: ranks are unique
             s_val[buf][wave] = wbest;
-            s_rec[buf][wave] = mine;
+            s_rec[buf][wave] = make_float4(xa, ya, za, __uint_as_float(rmin));
         }
         EPNET_STAMP(t3);
         __syncthreads();
@@ -539,8 +565,7 @@ __global__ __launch_bounds__(64 * kW) void fps_pruned_kernel(int n, int m, const
         const int bmx = period_max<kW>(wv);
         const unsigned r2 = (wv == bmx) ? __float_as_uint(rec.w) : 0xFFFFFFFFu;
         const unsigned r2min = period_min<kW>(r2);
-        // the winning record sits in lanes l with (l & (kW-1)) == its wave: spread it with a masked max
-        const bool win = r2 == r2min;
+        const bool win = r2 == r2min;  // one lane per period; spread its record with a masked max
         cx = __int_as_float(period_max<kW>(win ? __float_as_int(rec.x) : (int)0x80000000));
         cy = __int_as_float(period_max<kW>(win ? __float_as_int(rec.y) : (int)0x80000000));
         cz = __int_as_float(period_max<kW>(win ? __float_as_int(rec.z) : (int)0x80000000));
@@ -560,7 +585,7 @@ __global__ __launch_bounds__(64 * kW) void fps_pruned_kernel(int n, int m, const
     }
     if (temp) {
         for (int j = 0; j < PPT; ++j) {
-            const unsigned rk = rank16[((j * kW + wave) << 6) | lane];
+            const unsigned rk = (rk2[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
             if (rk != 0xFFFFu) temp[unrank14(rk)] = __int_as_float(t[j]);
         }
     }
@@ -661,19 +686,28 @@ extern "C" int epnet_furthest_point_sampling(int b, int n, int m, const float *x
     const int J = div_up(n, bs_ref);
     // 1024 < n <= 16384: exact spatially-pruned kernel (EPNET_FPS_PRUNE=0 forces the brute-force path)
     static const bool prune_enabled = !(getenv("EPNET_FPS_PRUNE") && atoi(getenv("EPNET_FPS_PRUNE")) == 0);
-    static const int prune_min = getenv("EPNET_FPS_PRUNE_MIN") ? atoi(getenv("EPNET_FPS_PRUNE_MIN")) : 4096;
+    static const int prune_min = getenv("EPNET_FPS_PRUNE_MIN") ? atoi(getenv("EPNET_FPS_PRUNE_MIN")) : 1024;
     if (prune_enabled && n > 1024 && n > prune_min && n <= 16384 && m > 1) {
-        // buckets of 64 points: 4 waves x {8,16,32} slots, 8 waves x 32 slots above 8192 points
-        const int waves = n > 8192 ? 8 : 4;
+        // 64-point slots: 4 waves x {8,16,32} slots, 8 waves above 8192 points (EPNET_FPS_PWAVES overrides)
+        int waves = n > 8192 ? 8 : 4;
+        if (const char *e = getenv("EPNET_FPS_PWAVES")) {
+            const int w = atoi(e);
+            if ((w == 4 || w == 8) && div_up(n, 64 * w) <= 32 && div_up(n, 64 * w) >= 1) waves = w;
+        }
         const int ppt_need = div_up(n, 64 * waves);
         const int ppt = ppt_need <= 8 ? 8 : ppt_need <= 16 ? 16 : 32;
         const size_t lds = (size_t)64 * waves * ppt * sizeof(unsigned long long);
 #define EPNET_FPS_PRUNED(W_, P_) \
     hipLaunchKernelGGL((pruned::fps_pruned_kernel<W_, P_>), grid, dim3(64 * W_), lds, s, n, m, xyz, temp, idx)
-        if (waves == 8) EPNET_FPS_PRUNED(8, 32);
-        else if (ppt == 8) EPNET_FPS_PRUNED(4, 8);
-        else if (ppt == 16) EPNET_FPS_PRUNED(4, 16);
-        else EPNET_FPS_PRUNED(4, 32);
+        if (waves == 8) {
+            if (ppt == 8) EPNET_FPS_PRUNED(8, 8);
+            else if (ppt == 16) EPNET_FPS_PRUNED(8, 16);
+            else EPNET_FPS_PRUNED(8, 32);
+        } else {
+            if (ppt == 8) EPNET_FPS_PRUNED(4, 8);
+            else if (ppt == 16) EPNET_FPS_PRUNED(4, 16);
+            else EPNET_FPS_PRUNED(4, 32);
+        }
 #undef EPNET_FPS_PRUNED
         return check_launch("furthest_point_sampling");
     }
