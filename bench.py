@@ -119,7 +119,7 @@ def op_family(name, head):
         return "gather", b * (m * 4 + c * n * 4 + c * m * 4)
     if name.startswith("ball_query"):
         b, n, m, _r, ns = head[:5]
-        return "ball_query", b * (n * 12 + m * 12 + m * ns * 4)
+        return "ball_query N=%d M=%d r=%g ns=%d" % (n, m, _r, ns), b * (n * 12 + m * 12 + m * ns * 4)
     if name.startswith("group_points_w"):
         b, c, n, m, ns = head[:5]
         return ("group_xyz" if c == 3 else "group_feat"), b * (m * ns * 4 + c * n * 4 + c * m * ns * 4)

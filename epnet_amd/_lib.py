@@ -26,6 +26,8 @@ SIGNATURES = {
     "epnet_gather_points": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "epnet_gather_points_grad": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "epnet_ball_query": (_i, [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
+    "epnet_ball_query_workspace_bytes": (_sz, [_i, _i, _i]),
+    "epnet_ball_query_ws": (_i, [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "epnet_group_points": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "epnet_group_points_grad": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "epnet_three_nn": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -11,6 +11,7 @@
 //
 // d2 = (cx-x)*(cx-x) + (cy-y)*(cy-y) + (cz-z)*(cz-z) in source order, no contraction; strict '<'.
 #include "common.h"
+#include "spatial.h"
 
 namespace epnet {
 
@@ -98,6 +99,140 @@ __global__ __launch_bounds__(kBqThreads) void ball_query_kernel(int n, int m, fl
     }
 }
 
+
+// ---- indexed path ----------------------------------------------------------------------------------
+//
+// For the big levels (N up to 16384) the scan is N*M pair tests although a ball only ever contains a
+// handful of points. With caller-supplied scratch the query is split in two launches:
+//   bq_index_kernel  one workgroup per scene sorts the points by grid cell (counting sort on an interleaved cell code)
+//                    and writes them, with their ORIGINAL index, as float4 plus one bounding box per
+//                    bucket of 64 consecutive sorted points;
+//   bq_query_kernel  one wave per centre: the lanes test the buckets' boxes against the ball (the lower
+//                    bound |clamp(c, box) - c|^2 uses the point-test expression, so by monotonicity of
+//                    fp32 arithmetic no bucket holding a hit is ever skipped), the few surviving
+//                    buckets are tested point by point, and every hit sets bit `original index` in an
+//                    N-bit LDS bitmap. Reading the bitmap back in order yields exactly the reference's
+//                    result: the first nsample hits in index order, padded with the first one.
+// The point test is the same expression as above: d2 = (cx-x)*(cx-x) + (cy-y)*(cy-y) + (cz-z)*(cz-z).
+
+constexpr int kIxThreads = 1024;
+constexpr int kIxMaxPoints = 16384;
+
+__global__ __launch_bounds__(kIxThreads) void bq_index_kernel(int n, int np, const float *__restrict__ xyz,
+                                                              float4 *__restrict__ sorted, float *__restrict__ boxes) {
+    extern __shared__ int s_dyn[];  // cell histogram, then np 16-bit indices in cell order
+    __shared__ float s_box[6][16];
+    __shared__ int s_part[16];
+    int *hist = s_dyn;
+    unsigned short *perm = reinterpret_cast<unsigned short *>(s_dyn + cell_hist_words(kIxThreads));
+    const int q = threadIdx.x, lane = q & 63;
+    xyz += (size_t)blockIdx.x * n * 3;
+    sorted += (size_t)blockIdx.x * np;
+    boxes += (size_t)blockIdx.x * (np / 64) * 6;
+    float lo[3], ext[3];
+    block_bbox3(xyz, n, s_box, lo, ext);
+    const CellGrid g = make_cell_grid(lo, ext);
+    cell_sort_lds(xyz, n, g, hist, s_part, perm);
+    for (int p = q; p < np; p += kIxThreads) {  // one wave handles one bucket at a time
+        const bool real = p < n;
+        const int k = real ? (int)perm[p] : 0;
+        float4 v = make_float4(3.0e38f, 3.0e38f, 3.0e38f, __int_as_float(-1));  // padding: never inside a ball
+        if (real) v = make_float4(xyz[k * 3 + 0], xyz[k * 3 + 1], xyz[k * 3 + 2], __int_as_float(k));
+        sorted[p] = v;
+        float mn[3] = {real ? v.x : 3.4e38f, real ? v.y : 3.4e38f, real ? v.z : 3.4e38f};
+        float mx[3] = {real ? v.x : -3.4e38f, real ? v.y : -3.4e38f, real ? v.z : -3.4e38f};
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                mn[a] = fminf(mn[a], __shfl_xor(mn[a], off, 64));
+                mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off, 64));
+            }
+        if (lane == 0) {
+            float *bx = boxes + (p >> 6) * 6;
+            const bool any = mn[0] <= mx[0];  // an all-padding bucket gets a box no ball can reach
+            bx[0] = any ? mn[0] : 3.0e38f; bx[1] = any ? mx[0] : 3.0e38f;
+            bx[2] = any ? mn[1] : 3.0e38f; bx[3] = any ? mx[1] : 3.0e38f;
+            bx[4] = any ? mn[2] : 3.0e38f; bx[5] = any ? mx[2] : 3.0e38f;
+        }
+    }
+}
+
+constexpr int kQThreads = 256;
+
+// DPL = bitmap dwords per lane = np / 2048 (np >= 2048)
+template <int DPL>
+__global__ __launch_bounds__(kQThreads) void bq_query_kernel(int np, int m, float radius2, int nsample,
+                                                             const float *__restrict__ new_xyz,
+                                                             const float4 *__restrict__ sorted,
+                                                             const float *__restrict__ boxes, int *__restrict__ idx) {
+    __shared__ unsigned s_bits[kQThreads / 64][64 * DPL];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bs = blockIdx.y;
+    const int ci = blockIdx.x * (kQThreads / 64) + wave;
+    if (ci >= m) return;  // wave-uniform; no block-level barrier below
+    sorted += (size_t)bs * np;
+    boxes += (size_t)bs * (np / 64) * 6;
+    const float *c = new_xyz + ((size_t)bs * m + ci) * 3;
+    const float cx = c[0], cy = c[1], cz = c[2];
+    int *out = idx + ((size_t)bs * m + ci) * nsample;
+    unsigned *bits = s_bits[wave];
+#pragma unroll
+    for (int w = 0; w < DPL; ++w) bits[lane * DPL + w] = 0u;
+
+    const int nb = np >> 6;  // buckets, a multiple of 32 (np >= 2048)
+    for (int b0 = 0; b0 < nb; b0 += 64) {
+        const int b = b0 + lane;
+        bool near = false;
+        if (b < nb) {
+            const float *bx = boxes + b * 6;
+            const float px = __builtin_amdgcn_fmed3f(cx, bx[0], bx[1]), py = __builtin_amdgcn_fmed3f(cy, bx[2], bx[3]),
+                        pz = __builtin_amdgcn_fmed3f(cz, bx[4], bx[5]);
+            const float dx = cx - px, dy = cy - py, dz = cz - pz;
+            near = (dx * dx + dy * dy + dz * dz) < radius2;
+        }
+        unsigned long long cand = __ballot(near);
+        while (cand) {
+            const int bb = b0 + (int)__builtin_ctzll(cand);
+            cand &= cand - 1ull;
+            const float4 p = sorted[(bb << 6) + lane];
+            const float dx = cx - p.x, dy = cy - p.y, dz = cz - p.z;
+            const float d2 = dx * dx + dy * dy + dz * dz;
+            if (d2 < radius2) {
+                const int k = __float_as_int(p.w);
+                atomicOr(&bits[k >> 5], 1u << (k & 31));
+            }
+        }
+    }
+    // read the bitmap back in index order: lane l owns bits [l*32*DPL, (l+1)*32*DPL)
+    unsigned w[DPL];
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) {
+        w[i] = bits[lane * DPL + i];
+        cnt += __popc(w[i]);
+    }
+    const int incl = wave_inclusive_scan(cnt);
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    int pos = incl - cnt;
+    int mine_first = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) {
+        unsigned ww = w[i];
+        if (ww && mine_first == 0x7fffffff) mine_first = (lane * DPL + i) * 32 + (int)__builtin_ctz(ww);
+        while (ww && pos < nsample) {
+            const int bit = (int)__builtin_ctz(ww);
+            ww &= ww - 1u;
+            out[pos++] = (lane * DPL + i) * 32 + bit;
+        }
+    }
+    // padding with the first hit (ball_query_gpu.cu:35-39); an empty ball is all zeros
+    const unsigned long long have = __ballot(cnt > 0);
+    int first = 0;
+    if (have) first = __builtin_amdgcn_readlane(mine_first, (int)__builtin_ctzll(have));
+    for (int l = total + lane; l < nsample; l += 64) out[l] = first;
+}
+
 }  // namespace epnet
 
 using namespace epnet;
@@ -121,4 +256,46 @@ extern "C" int epnet_ball_query(int b, int n, int m, float radius, int nsample, 
         hipLaunchKernelGGL(ball_query_kernel<1>, grid, dim3(kBqThreads), 0, s, n, m, radius2, nsample, new_xyz, xyz, idx);
     }
     return check_launch("ball_query");
+}
+
+static size_t bq_index_lds(int np) { return (size_t)(kCells + kCells / (kCells / kIxThreads) + 64) * sizeof(int) + (size_t)np * 2; }
+
+static int bq_padded(int n) {
+    int np = 2048;
+    while (np < n) np <<= 1;
+    return np;
+}
+
+extern "C" size_t epnet_ball_query_workspace_bytes(int b, int n, int m) {
+    if (b <= 0 || n < 2048 || n > kIxMaxPoints || m <= 0) return 0;  // small or huge scenes: direct scan, no scratch
+    const size_t np = (size_t)bq_padded(n);
+    return (size_t)b * (np * sizeof(float4) + (np / 64) * 6 * sizeof(float));
+}
+
+extern "C" int epnet_ball_query_ws(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                                   const float *xyz, int *idx, void *workspace, size_t workspace_bytes,
+                                   epnet_stream_t stream) {
+    const size_t need = epnet_ball_query_workspace_bytes(b, n, m);
+    if (need == 0 || nsample <= 0) return epnet_ball_query(b, n, m, radius, nsample, new_xyz, xyz, idx, stream);
+    EPNET_REQUIRE(new_xyz && xyz && idx && workspace);
+    if (workspace_bytes < need) return EPNET_ENOMEM;
+    if (((uintptr_t)workspace & 15) != 0) return EPNET_EINVAL;
+    EPNET_REQUIRE(b <= 65535);
+    hipStream_t s = (hipStream_t)stream;
+    const int np = bq_padded(n);
+    float4 *sorted = (float4 *)workspace;
+    float *boxes = (float *)(sorted + (size_t)b * np);
+    hipLaunchKernelGGL(bq_index_kernel, dim3(b), dim3(kIxThreads), bq_index_lds(np), s, n, np, xyz,
+                       sorted, boxes);
+    int rc = check_launch("ball_query index");
+    if (rc) return rc;
+    const float radius2 = radius * radius;  // ball_query_gpu.cu:23
+    dim3 grid(div_up(m, kQThreads / 64), b);
+    switch (np / 2048) {
+        case 1: hipLaunchKernelGGL(bq_query_kernel<1>, grid, dim3(kQThreads), 0, s, np, m, radius2, nsample, new_xyz, sorted, boxes, idx); break;
+        case 2: hipLaunchKernelGGL(bq_query_kernel<2>, grid, dim3(kQThreads), 0, s, np, m, radius2, nsample, new_xyz, sorted, boxes, idx); break;
+        case 4: hipLaunchKernelGGL(bq_query_kernel<4>, grid, dim3(kQThreads), 0, s, np, m, radius2, nsample, new_xyz, sorted, boxes, idx); break;
+        default: hipLaunchKernelGGL(bq_query_kernel<8>, grid, dim3(kQThreads), 0, s, np, m, radius2, nsample, new_xyz, sorted, boxes, idx); break;
+    }
+    return check_launch("ball_query query");
 }

@@ -31,6 +31,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "spatial.h"
 
 // clang exposes no builtin for v_writelane_b32; bind the LLVM intrinsic by name (value, lane, old)
 extern "C" __device__ int epnet_llvm_writelane_i32(int, int, int) __asm("llvm.amdgcn.writelane.i32");
@@ -249,8 +250,8 @@ __global__ __launch_bounds__(64 * W) void fps_wave_kernel(int n, int m, int lg_b
 
 // ---- pruned kernel ------------------------------------------------------------------------------
 //
-// Exact FPS with spatial pruning, for 1024 < N <= 16384. The points are sorted along a Morton curve
-// (in-kernel bitonic sort in LDS) and dealt to "buckets" of 64 consecutive sorted points: bucket b is
+// Exact FPS with spatial pruning, for 1024 < N <= 16384. The points are sorted by grid cell
+// (in-kernel counting sort on an interleaved cell code, spatial.h) and dealt to "buckets" of 64 consecutive sorted points: bucket b is
 // slot b/W of wave b%W, one point per lane. A wave keeps, for each of its buckets j, a summary in LANE j
 // of a few registers (bounding box, maximum running distance bm, reference rank of the point holding
 // it) plus that point's coordinates in a small LDS table. A new sample c can only lower distances in
@@ -282,15 +283,6 @@ __device__ unsigned long long g_stats[16];
 #define EPNET_ACC(slot, a, b)
 #define EPNET_CNT(slot, v)
 #endif
-
-__device__ __forceinline__ unsigned spread10(unsigned v) {  // ..9876543210 -> ..9__8__7__6__5__4__3__2__1__0
-    v &= 0x3FFu;
-    v = (v | (v << 16)) & 0x030000FFu;
-    v = (v | (v << 8)) & 0x0300F00Fu;
-    v = (v | (v << 4)) & 0x030C30C3u;
-    v = (v | (v << 2)) & 0x09249249u;
-    return v;
-}
 
 __device__ __forceinline__ unsigned rank14(int k) { return (bitrev_lg((unsigned)k & 1023u, 10) << 4) | ((unsigned)k >> 10); }
 __device__ __forceinline__ int unrank14(unsigned r) { return (int)(bitrev_lg(r >> 4, 10) + ((r & 15u) << 10)); }
@@ -387,8 +379,11 @@ __global__ __launch_bounds__(64 * kW) void fps_pruned_kernel(int n, int m, const
     typedef unsigned vecr __attribute__((ext_vector_type(PPT / 2)));
     constexpr int kT = 64 * kW;
     constexpr int NP = kT * PPT;  // padded point count (power of two)
-    extern __shared__ unsigned long long s_sort[];  // NP sort keys: (morton << 16) | k
-    __shared__ float s_box[6][8];
+    extern __shared__ int s_dyn[];  // cell histogram, then NP 16-bit point indices in cell order
+    int *hist = s_dyn;
+    unsigned short *perm = reinterpret_cast<unsigned short *>(s_dyn + kCells + kCells / (kCells / kT) + 64);
+    __shared__ int s_part[16];
+    __shared__ float s_box[6][16];
     __shared__ int s_val[2][16];
     __shared__ float4 s_rec[2][16];
     __shared__ int s_idx[kIdxBuf];
@@ -400,69 +395,11 @@ __global__ __launch_bounds__(64 * kW) void fps_pruned_kernel(int n, int m, const
     idxs += (size_t)blockIdx.x * m;
     const int kNeg1 = __float_as_int(-1.f);
 
-    // ---- scene bounding box
-    float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
-    for (int k = q; k < n; k += kT)
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const float v = xyz[k * 3 + a];
-            lo[a] = fminf(lo[a], v);
-            hi[a] = fmaxf(hi[a], v);
-        }
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            lo[a] = fminf(lo[a], __shfl_xor(lo[a], off, 64));
-            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off, 64));
-        }
-        if (lane == 0) {
-            s_box[a][wave] = lo[a];
-            s_box[3 + a][wave] = hi[a];
-        }
-    }
-    __syncthreads();
-    float ext = 0.f;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        float l = s_box[a][0], h = s_box[3 + a][0];
-#pragma unroll
-        for (int w = 1; w < kW; ++w) {
-            l = fminf(l, s_box[a][w]);
-            h = fmaxf(h, s_box[3 + a][w]);
-        }
-        lo[a] = l;
-        ext = fmaxf(ext, h - l);
-    }
-    const float scale = ext > 0.f ? 1023.f / ext : 0.f;  // one cell size for all axes
-
-    // ---- Morton keys, bitonic sort (ascending); padding keys sort last
-    for (int k = q; k < NP; k += kT) {
-        unsigned long long key = ~0ull;
-        if (k < n) {
-            const unsigned ix = (unsigned)fminf((xyz[k * 3 + 0] - lo[0]) * scale, 1023.f);
-            const unsigned iy = (unsigned)fminf((xyz[k * 3 + 1] - lo[1]) * scale, 1023.f);
-            const unsigned iz = (unsigned)fminf((xyz[k * 3 + 2] - lo[2]) * scale, 1023.f);
-            const unsigned code = spread10(ix) | (spread10(iy) << 1) | (spread10(iz) << 2);
-            key = ((unsigned long long)code << 16) | (unsigned long long)k;
-        }
-        s_sort[k] = key;
-    }
-    __syncthreads();
-    for (int k2 = 2; k2 <= NP; k2 <<= 1)
-        for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-            for (int i = q; i < NP / 2; i += kT) {
-                const int a = ((i & ~(j2 - 1)) << 1) | (i & (j2 - 1));
-                const int b = a | j2;
-                const unsigned long long ka = s_sort[a], kb = s_sort[b];
-                const bool up = (a & k2) == 0;
-                if ((ka > kb) == up) {
-                    s_sort[a] = kb;
-                    s_sort[b] = ka;
-                }
-            }
-            __syncthreads();
-        }
+    // ---- spatial order: counting sort by grid cell (spatial.h); positions >= n are padding
+    float lo[3], ext[3];
+    block_bbox3(xyz, n, s_box, lo, ext);
+    const CellGrid grid = make_cell_grid(lo, ext);
+    cell_sort_lds(xyz, n, grid, hist, s_part, perm);
 
     // ---- sorted position p = (group << 6 | lane); group g of 64 sorted points -> (wave g % kW, slot g / kW)
     vecf x, y, z;
@@ -470,10 +407,10 @@ __global__ __launch_bounds__(64 * kW) void fps_pruned_kernel(int n, int m, const
     vecr rk2;  // reference ranks of this thread's points, two 16-bit values per register (0xFFFF = padding)
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
-        const unsigned long long key = s_sort[((j * kW + wave) << 6) | lane];
+        const int p = ((j * kW + wave) << 6) | lane;
         unsigned r16 = 0xFFFFu;
-        if (key != ~0ull) {
-            const int k = (int)(key & 0xFFFFull);
+        if (p < n) {
+            const int k = (int)perm[p];
             r16 = rank14(k);
             x[j] = xyz[k * 3 + 0];
             y[j] = xyz[k * 3 + 1];
@@ -696,7 +633,7 @@ extern "C" int epnet_furthest_point_sampling(int b, int n, int m, const float *x
         }
         const int ppt_need = div_up(n, 64 * waves);
         const int ppt = ppt_need <= 8 ? 8 : ppt_need <= 16 ? 16 : 32;
-        const size_t lds = (size_t)64 * waves * ppt * sizeof(unsigned long long);
+        const size_t lds = (size_t)(kCells + kCells / (kCells / (64 * waves)) + 64) * sizeof(int) + (size_t)64 * waves * ppt * 2;
 #define EPNET_FPS_PRUNED(W_, P_) \
     hipLaunchKernelGGL((pruned::fps_pruned_kernel<W_, P_>), grid, dim3(64 * W_), lds, s, n, m, xyz, temp, idx)
         if (waves == 8) {

@@ -18,8 +18,14 @@ def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
     """ball_query_wrapper_fast, pointnet2_lib/pointnet2/src/ball_query.cpp:14-25"""
     pn, px, pi = dev_ptr(new_xyz, "new_xyz", _F), dev_ptr(xyz, "xyz", _F), dev_ptr(idx, "idx", _I)
     need(new_xyz, b * m * 3, "new_xyz"); need(xyz, b * n * 3, "xyz"); need(idx, b * m * nsample, "idx")
+    l = _lib.lib()
+    ws_bytes = l.epnet_ball_query_workspace_bytes(b, n, m)
     with on_device_of(xyz) as s:
-        _lib.check(_lib.lib().epnet_ball_query(b, n, m, radius, nsample, pn, px, pi, s), "ball_query")
+        if ws_bytes:  # scratch from torch's caching allocator lets the library index the scene spatially
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=xyz.device)
+            _lib.check(l.epnet_ball_query_ws(b, n, m, radius, nsample, pn, px, pi, ws.data_ptr(), ws_bytes, s), "ball_query")
+        else:
+            _lib.check(l.epnet_ball_query(b, n, m, radius, nsample, pn, px, pi, s), "ball_query")
     return 1
 
 

@@ -74,6 +74,14 @@ int epnet_gather_points_grad(int b, int c, int n, int npoints, const float *grad
 int epnet_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
                      const float *xyz, int *idx, epnet_stream_t stream);
 
+/* Same result as epnet_ball_query, with caller-supplied device scratch (16-byte aligned) that lets the
+ * library index the scene spatially (Morton-sorted copy + per-bucket boxes) instead of scanning all N
+ * points per centre; bit-identical output. epnet_ball_query_workspace_bytes() == 0 means the direct scan
+ * is used anyway (small or very large scenes) and workspace may be NULL. */
+size_t epnet_ball_query_workspace_bytes(int b, int n, int m);
+int epnet_ball_query_ws(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
+                        int *idx, void *workspace, size_t workspace_bytes, epnet_stream_t stream);
+
 /* group_points_kernel_launcher_fast, group_points_gpu.cu:69-86.
  * points (B,C,N), idx (B,M,ns) -> out (B,C,M,ns) */
 int epnet_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
