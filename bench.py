@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--points", type=int, default=16384)
     ap.add_argument("--kind", default="kitti", choices=["kitti", "ubox", "dup"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="single stream: do not run ball query / grouping of level l beside the FPS of level l+1")
     ap.add_argument("--with-fp", action="store_true", help="also run the 4 three_nn + 4 three_interpolate FP ops")
     ap.add_argument("--cpu-scenes", type=int, default=int(os.environ.get("EPNET_BENCH_CPU_SCENES", "16")),
                     help="scenes in the cpu_baseline sample (0 = skip)")
@@ -132,6 +134,17 @@ def op_family(name, head):
     return name, 0
 
 
+def pmc_traffic(family, args):
+    """HBM bytes per launch of the dominant kernel from the committed PMC profile (collected at 16 kitti
+    scenes per launch; per-scene figure x scenes). None when no matching profile exists."""
+    symbol = {"fps N=16384 M=4096": "epnet::pruned::fps_pruned_kernel<8, 32>"}.get(family)
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if symbol is None or args.kind != "kitti" or args.points != 16384 or not os.path.exists(path):
+        return None
+    k = json.load(open(path))["kernels"].get(symbol)
+    return None if k is None else int(k["hbm_bytes_avg"] / 16 * args.batch)
+
+
 def main():
     args = parse()
     import torch
@@ -161,7 +174,8 @@ def main():
     def time_stack(batch, steps, warmup):
         """returns (seconds for `steps` steps, the stack, its input)"""
         xyz = synth.scenes(args.kind, batch, args.points, seed=1 + rank * 100003).to(dev)   # inputs resident in HBM
-        stack = sa_stack.SAStack(batch, n=args.points, device=dev, with_fp=args.with_fp, seed=rank)
+        stack = sa_stack.SAStack(batch, n=args.points, device=dev, with_fp=args.with_fp, seed=rank,
+                                 overlap=not args.no_overlap)
         if args.no_graph:
             step = lambda: stack.run(xyz)
         else:
@@ -185,6 +199,7 @@ def main():
     value = points_per_step * args.steps / elapsed
 
     # ---- per-kernel durations: the same K steps replayed eagerly with HIP events around every launch
+    stack.overlap = False  # single stream here, so that an event pair brackets exactly its own kernel
     with OpTimer(torch, ext) as timer:
         for _ in range(args.steps):
             stack.run(xyz)
@@ -205,8 +220,11 @@ def main():
                           "bytes_per_launch": f["bytes"] // f["launches"], "GBps": round(gbs, 2)}
     dominant = max(kernels, key=lambda k: kernels[k]["step_ms"])
     dk = kernels[dominant]
+    traffic = pmc_traffic(dominant, args)
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": dk["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(dk["GBps"] / HBM_PEAK_GBS, 6), "traffic": None,
+                "frac": round(dk["GBps"] / HBM_PEAK_GBS, 6), "traffic": traffic,
+                "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at 16 scenes, "
+                                  "scaled by scenes per launch)" if traffic else None,
                 "note": "FPS is a chain of M-1 dependent arg-max iterations per scene (latency bound), one workgroup "
                         "per scene; the bandwidth-bound kernels are group_feat/group_xyz, see 'kernels'"}
     stack_bytes = sa_stack.sa_algorithmic_bytes(args.points)["total"] + (sa_stack.fp_algorithmic_bytes()["total"] if args.with_fp else 0)

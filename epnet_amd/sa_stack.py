@@ -54,8 +54,14 @@ def fp_algorithmic_bytes(fp=RPN_FP):
 
 class SAStack:
     def __init__(self, batch, n=16384, device="cuda", npoints=RPN_NPOINTS, radii=RPN_RADII, nsamples=RPN_NSAMPLES,
-                 feat_channels=RPN_FEAT_CHANNELS, with_fp=False, fp=RPN_FP, seed=0):
+                 feat_channels=RPN_FEAT_CHANNELS, with_fp=False, fp=RPN_FP, seed=0, overlap=True):
         self.batch, self.n = batch, n
+        # overlap: FPS/gather of level l+1 depend only on the centres of level l (never on features), so
+        # the sampling chain runs ahead on the launch stream while ball query + grouping of each level
+        # follow on a second HIP stream (the SA levels' FPS is a latency-bound one-workgroup-per-scene
+        # kernel that leaves the rest of the chip idle)
+        self.overlap = overlap
+        self.side = None
         self.npoints, self.radii, self.nsamples, self.feat_channels = npoints, radii, nsamples, feat_channels
         self.with_fp, self.fp = with_fp, fp
         dev = torch.device(device)
@@ -97,9 +103,20 @@ class SAStack:
         self.graph = None
         self.static_xyz = None
 
+    def _group_level(self, L, cur_xyz):
+        b, n, m = self.batch, L["n"], L["m"]
+        for S in L["scales"]:
+            ext.ball_query_wrapper(b, n, m, S["radius"], S["ns"], L["new_xyz"], cur_xyz, S["idx"])
+            ext.group_points_wrapper(b, 3, n, m, S["ns"], L["xyz_t"], S["idx"], S["grouped_xyz"])
+            if L["c"]:
+                ext.group_points_wrapper(b, L["c"], n, m, S["ns"], L["features"], S["idx"], S["grouped_feat"])
+
     def run(self, xyz):
         """xyz (B,N,3) contiguous fp32 on the stack's device; all outputs land in self.levels"""
         b = self.batch
+        main = torch.cuda.current_stream(xyz.device)
+        if self.overlap and self.side is None:
+            self.side = torch.cuda.Stream(device=xyz.device)
         cur_xyz = xyz
         for L in self.levels:
             n, m = L["n"], L["m"]
@@ -108,12 +125,15 @@ class SAStack:
             ext.furthest_point_sampling_wrapper(b, n, m, cur_xyz, L["temp"], L["fps_idx"])
             ext.gather_points_wrapper(b, 3, n, m, L["xyz_t"], L["fps_idx"], L["new_xyz_t"])
             L["new_xyz"].copy_(L["new_xyz_t"].transpose(1, 2))   # pointnet2_modules.py:42-45
-            for S in L["scales"]:
-                ext.ball_query_wrapper(b, n, m, S["radius"], S["ns"], L["new_xyz"], cur_xyz, S["idx"])
-                ext.group_points_wrapper(b, 3, n, m, S["ns"], L["xyz_t"], S["idx"], S["grouped_xyz"])
-                if L["c"]:
-                    ext.group_points_wrapper(b, L["c"], n, m, S["ns"], L["features"], S["idx"], S["grouped_feat"])
+            if self.overlap:
+                self.side.wait_stream(main)
+                with torch.cuda.stream(self.side):
+                    self._group_level(L, cur_xyz)
+            else:
+                self._group_level(L, cur_xyz)
             cur_xyz = L["new_xyz"]
+        if self.overlap:
+            main.wait_stream(self.side)
         if self.with_fp:
             # FP modules walk back up: unknown = xyz of the finer level, known = the coarser one
             xyzs = [xyz] + [L["new_xyz"] for L in self.levels]

@@ -142,6 +142,31 @@ def test_ball_query_writes_every_slot_and_boundary_is_strict(oracle):
     assert host(idx).tolist() == [[[63, 64, 65, 63, 63, 63], [0, 0, 0, 0, 0, 0]]]
 
 
+def test_ball_query_indexed_and_direct_paths_agree(oracle):
+    """epnet_ball_query (direct scan) and epnet_ball_query_ws (spatially indexed, caller scratch) are two
+    entry points of the C ABI with bit-identical output; the workspace contract is checked too"""
+    from epnet_amd import _lib
+    l = _lib.lib()
+    for b, n, m, radius, ns, kind in ((2, 4096, 513, 0.8, 24, "kitti"), (1, 16384, 1000, 0.3, 16, "dup"), (2, 3000, 77, 1.0, 40, "ubox")):
+        xyz = rand_cloud(b, n, seed=31 + n, kind=kind)
+        centres = np.ascontiguousarray(xyz[:, np.random.default_rng(3).permutation(n)[:m]])
+        centres[:, 0] += 500.0  # an empty ball
+        dx, dc = dev(xyz), dev(centres)
+        want = oracle.ball_query(radius, ns, xyz, centres)
+        direct = torch.full((b, m, ns), -3, dtype=torch.int32, device=DEV)
+        assert l.epnet_ball_query(b, n, m, radius, ns, dc.data_ptr(), dx.data_ptr(), direct.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+        nbytes = l.epnet_ball_query_workspace_bytes(b, n, m)
+        assert nbytes > 0
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=DEV)
+        indexed = torch.full((b, m, ns), -3, dtype=torch.int32, device=DEV)
+        stream = torch.cuda.current_stream().cuda_stream
+        assert l.epnet_ball_query_ws(b, n, m, radius, ns, dc.data_ptr(), dx.data_ptr(), indexed.data_ptr(), ws.data_ptr(), nbytes, stream) == 0
+        assert l.epnet_ball_query_ws(b, n, m, radius, ns, dc.data_ptr(), dx.data_ptr(), indexed.data_ptr(), ws.data_ptr(), nbytes - 16, stream) == -3  # ENOMEM
+        np.testing.assert_array_equal(host(direct), want)
+        np.testing.assert_array_equal(host(indexed), want)
+    assert l.epnet_ball_query_workspace_bytes(4, 512, 128) == 0 and l.epnet_ball_query_workspace_bytes(1, 65536, 16384) == 0
+
+
 def test_ball_query_full_size_property():
     """config 5 shape on a reduced batch: 65536 points, 16384 centres, nsample 64: every index lies in
     the ball or is the padding value, and the hits are strictly increasing."""
