@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""bench_ops.py -- per-operator timings of the hot-path rows that are not part of bench.py's SA stack:
+iou3d (rotated overlap / IoU, both NMS flavours), roipool3d, three_nn / three_interpolate and the three
+gradient ops, at the shapes of the reference's rcnn_online step. One JSON line per op:
+median HIP-event time, algorithmic bytes (SURVEY.md 8d formulas) and the resulting GB/s.
+
+    python bench_ops.py [--reps 20]
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=20)
+    args = ap.parse_args()
+    import torch
+    from epnet_amd import iou3d_cuda, iou3d_utils, kitti_utils, pointnet2_cuda as p2, roipool3d_cuda, synth
+
+    dev = torch.device("cuda:0")
+    f32, i32 = torch.float32, torch.int32
+
+    def timeit(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(args.reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        ts.sort()
+        return ts[len(ts) // 2]
+
+    def report(op, shape, ms, nbytes, note=""):
+        print(json.dumps({"op": op, "shape": shape, "ms": round(ms, 4), "algorithmic_bytes": nbytes,
+                          "GBps": round(nbytes / (ms * 1e-3) / 1e9, 2), "note": note}), flush=True)
+
+    g = torch.Generator().manual_seed(0)
+    # ---- NMS at the proposal-layer sizes (RPN.NMS_TYPE normal, N <= 6300 / 2700, thresh 0.85) and eval rotated NMS
+    for n, rot, thr in ((6300, False, 0.85), (2700, False, 0.85), (6300, True, 0.8), (512, True, 0.1), (100, True, 0.1)):
+        boxes, scores = synth.proposal_boxes(n, seed=n, num_objects=40, jitter=1.5)
+        bev, sc = kitti_utils.boxes3d_to_bev_torch(boxes).to(dev), scores.to(dev)
+        fn = iou3d_utils.nms_gpu if rot else iou3d_utils.nms_normal_gpu
+        kept = fn(bev, sc, thr)
+        ms = timeit(lambda: fn(bev, sc, thr))
+        srt = bev[sc.sort(0, descending=True)[1]].contiguous()
+        dfn = iou3d_cuda.nms_device if rot else iou3d_cuda.nms_normal_device
+        ms_dev = timeit(lambda: dfn(srt, thr))
+        report("nms_gpu" if rot else "nms_normal_gpu", {"N": n, "thresh": thr, "kept": int(kept.numel())}, ms,
+               n * 20 + n * ((n + 63) // 64) * 8, "surface call incl. sort + 4-byte count sync; mask+sweep kernels alone %.4f ms" % ms_dev)
+    # ---- 3-D IoU of 512 ROIs x 20 GT boxes, and the 1x1 calls of aug_roi_by_noise
+    a, _ = synth.proposal_boxes(512, seed=1)
+    b, _ = synth.proposal_boxes(20, seed=2)
+    a, b = a.to(dev), b.to(dev)
+    report("boxes_iou3d_gpu", {"Na": 512, "Nb": 20}, timeit(lambda: iou3d_utils.boxes_iou3d_gpu(a, b)), 512 * 20 + 20 * 20 + 512 * 20 * 4, "incl. torch height/volume math")
+    a1, b1 = a[:1].contiguous(), b[:1].contiguous()
+    report("boxes_iou3d_gpu", {"Na": 1, "Nb": 1}, timeit(lambda: iou3d_utils.boxes_iou3d_gpu(a1, b1)), 44, "launch-latency bound")
+    # ---- roipool3d: (B,16384,3)+(B,16384,130) -> (B,64,512,133)
+    for bsz, m in ((2, 64), (1, 100), (16, 64)):
+        pts = synth.scenes("kitti", bsz, 16384, seed=5).to(dev)
+        feat = torch.randn((bsz, 16384, 130), generator=g).to(dev)
+        boxes = torch.stack([synth.proposal_boxes(m, seed=50 + i)[0] for i in range(bsz)]).to(dev)
+        pooled = torch.zeros((bsz, m, 512, 133), dtype=f32, device=dev)
+        flag = torch.zeros((bsz, m), dtype=i32, device=dev)
+        big = kitti_utils.enlarge_box3d(boxes.view(-1, 7), 0.2).view(bsz, m, 7).contiguous()
+        ms = timeit(lambda: roipool3d_cuda.forward(pts, big, feat, pooled, flag))
+        n = 16384
+        report("roipool3d forward", {"B": bsz, "N": n, "M": m, "S": 512, "C": 130}, ms,
+               bsz * (n * 12 + n * 130 * 4 + m * 28 + m * 512 * 133 * 4 + m * 4), "empty boxes: %d" % int(flag.sum()))
+    # ---- FP ops
+    for bsz, (c, m, n) in ((16, (256, 4096, 16384)), (16, (512, 1024, 4096)), (1, (256, 4096, 16384))):
+        unknown = synth.scenes("kitti", bsz, n, seed=7).to(dev)
+        known = unknown[:, :m].contiguous()
+        d2 = torch.empty((bsz, n, 3), device=dev); idx = torch.empty((bsz, n, 3), dtype=i32, device=dev)
+        ms = timeit(lambda: p2.three_nn_wrapper(bsz, n, m, unknown, known, d2, idx))
+        report("three_nn", {"B": bsz, "n": n, "m": m}, ms, bsz * (n * 12 + m * 12 + n * 24))
+        feats = torch.randn((bsz, c, m), generator=g).to(dev)
+        w = torch.rand((bsz, n, 3), generator=g).to(dev); w = (w / w.sum(-1, keepdim=True)).contiguous()
+        out = torch.empty((bsz, c, n), device=dev)
+        ms = timeit(lambda: p2.three_interpolate_wrapper(bsz, c, m, n, feats, idx, w, out))
+        report("three_interpolate", {"B": bsz, "C": c, "m": m, "n": n}, ms, bsz * (c * m * 4 + n * 24 + c * n * 4))
+        go = torch.randn((bsz, c, n), generator=g).to(dev); gp = torch.zeros((bsz, c, m), device=dev)
+        ms = timeit(lambda: p2.three_interpolate_grad_wrapper(bsz, c, n, m, go, idx, w, gp))
+        report("three_interpolate_grad", {"B": bsz, "C": c, "n": n, "m": m}, ms, bsz * (c * n * 4 + n * 24 + c * m * 4))
+    # ---- grouping gradient (level 2: C=96, N=4096, M=1024, ns=32)
+    for bsz in (16,):
+        go = torch.randn((bsz, 96, 1024, 32), generator=g).to(dev)
+        idx = torch.randint(0, 4096, (bsz, 1024, 32), generator=g, dtype=i32).to(dev)
+        gp = torch.zeros((bsz, 96, 4096), device=dev)
+        ms = timeit(lambda: p2.group_points_grad_wrapper(bsz, 96, 4096, 1024, 32, go, idx, gp))
+        report("group_points_grad", {"B": bsz, "C": 96, "N": 4096, "M": 1024, "ns": 32}, ms, bsz * (96 * 1024 * 32 * 4 + 1024 * 32 * 4 + 96 * 4096 * 4))
+
+
+if __name__ == "__main__":
+    main()

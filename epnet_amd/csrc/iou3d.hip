@@ -8,7 +8,7 @@
 //   * box_overlap evaluates each polygon vertex's atan2 once and bubble-sorts on the stored
 //     angles (the reference recomputes two atan2 per comparison, :104-106, :188-196): the same
 //     deterministic function of the same arguments, hence the same swaps in the same order;
-//   * the NMS bit-mask is computed for the upper triangle of 64x64 tiles only -- the host sweep
+//   * the NMS bit-mask is computed for the upper triangle only, one wave per (row, 64-column tile) -- the host sweep
 //     (iou3d.cpp:111-114) never reads a word left of the diagonal;
 //   * the greedy sweep runs on the device (one workgroup): no cudaMalloc / 5 MB device->host
 //     copy / host loop per call (iou3d.cpp:87-116).
@@ -192,46 +192,45 @@ __global__ __launch_bounds__(256) void pairwise_bev_kernel(int num_a, const floa
     ans[(size_t)a_idx * num_b + b_idx] = IOU ? iou_bev(ba, bb, ta, tb) : box_overlap(ba, bb, ta, tb);
 }
 
-// suppression bit-mask, upper triangle of 64x64 tiles: one wave per (row tile <= col tile)
+// per-box trigonometry, once per box instead of once per pair
+__global__ __launch_bounds__(256) void box_trig_kernel(int n, const float *__restrict__ boxes, BoxTrig *__restrict__ trig) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) trig[i] = box_trig(boxes[i * 5 + 4]);
+}
+
+// suppression bit-mask, upper triangle only: one WAVE per (row, 64-column tile) -- each lane owns one
+// pair and the 64-bit mask word is the wave's ballot (the reference gives a thread a whole row of 64
+// pairs, :281-290)
 template <bool ROTATED>
-__global__ __launch_bounds__(64) void nms_mask_kernel(int boxes_num, float thresh, const float *__restrict__ boxes,
-                                                      unsigned long long *__restrict__ mask) {
-    const int row_start = blockIdx.y, col_start = blockIdx.x;
-    if (row_start > col_start) return;
-    const int row_size = min(boxes_num - row_start * 64, 64);
-    const int col_size = min(boxes_num - col_start * 64, 64);
-    __shared__ float block_boxes[64 * 5];
-    __shared__ BoxTrig block_trig[64];
-    const int t = threadIdx.x;
-    if (t < col_size) {
+__global__ __launch_bounds__(256) void nms_mask_kernel(int boxes_num, float thresh, const float *__restrict__ boxes,
+                                                       const BoxTrig *__restrict__ trig,
+                                                       unsigned long long *__restrict__ mask) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int col_blk = blockIdx.y;
+    if (row >= boxes_num || col_blk < (row >> 6)) return;  // wave-uniform: tiles left of the diagonal are never read
+    const int col = col_blk * 64 + lane;
+    bool over = false;
+    if (col < boxes_num && col > row) {  // on the diagonal tile only the bits right of the row itself (:281-283)
+        float cb[5], ob[5];
 #pragma unroll
-        for (int i = 0; i < 5; ++i) block_boxes[t * 5 + i] = boxes[(64 * col_start + t) * 5 + i];
-        if (ROTATED) block_trig[t] = box_trig(block_boxes[t * 5 + 4]);
-    }
-    __syncthreads();
-    if (t < row_size) {
-        const int cur = 64 * row_start + t;
-        float cb[5];
-#pragma unroll
-        for (int i = 0; i < 5; ++i) cb[i] = boxes[cur * 5 + i];
-        BoxTrig ct = {0.f, 0.f, 0.f, 0.f};
-        if (ROTATED) ct = box_trig(cb[4]);
-        unsigned long long bits = 0;
-        const int start = (row_start == col_start) ? t + 1 : 0;
-        for (int i = start; i < col_size; ++i) {
-            const float v = ROTATED ? iou_bev(cb, block_boxes + i * 5, ct, block_trig[i])
-                                    : iou_normal(cb, block_boxes + i * 5);
-            if (v > thresh) bits |= 1ull << i;
+        for (int i = 0; i < 5; ++i) {
+            cb[i] = boxes[row * 5 + i];
+            ob[i] = boxes[col * 5 + i];
         }
-        const int col_blocks = (boxes_num + 63) / 64;
-        mask[(size_t)cur * col_blocks + col_start] = bits;
+        const float v = ROTATED ? iou_bev(cb, ob, trig[row], trig[col]) : iou_normal(cb, ob);
+        over = v > thresh;
     }
+    const unsigned long long bits = __ballot(over);
+    const int col_blocks = (boxes_num + 63) / 64;
+    if (lane == 0) mask[(size_t)row * col_blocks + col_blk] = bits;
 }
 
 // Greedy sweep of iou3d.cpp:100-116 on the device, one workgroup. For each 64-box tile: wave 0
 // resolves the tile against its diagonal mask words (a 64-step scalar recurrence on readlane'd
-// words), appends the kept positions, then all threads OR the kept rows into the removed-set
-// words to the right of the tile.
+// words) and appends the kept positions; then ALL threads spread the (kept row, later column) mask
+// words of the tile over themselves -- independent, coalesced loads -- and OR them into the
+// removed-set words in LDS.
 constexpr int kSweepThreads = 1024;
 __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(int boxes_num,
                                                                   const unsigned long long *__restrict__ mask,
@@ -240,6 +239,7 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(int boxes_num,
     extern __shared__ unsigned long long remv[];  // col_blocks words
     __shared__ unsigned long long kept_bits;
     __shared__ int kept_total;
+    __shared__ unsigned char kept_rows[64];
     const int col_blocks = (boxes_num + 63) / 64;
     for (int j = threadIdx.x; j < col_blocks; j += kSweepThreads) remv[j] = 0ull;
     if (threadIdx.x == 0) kept_total = 0;
@@ -266,23 +266,24 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(int boxes_num,
                 }
             }
             const int base = kept_total;
-            if ((kept >> lane) & 1ull) keep[base + __popcll(kept & ((1ull << lane) - 1ull))] = blk * 64 + lane;
+            if ((kept >> lane) & 1ull) {
+                const int pos = (int)__popcll(kept & ((1ull << lane) - 1ull));
+                keep[base + pos] = blk * 64 + lane;
+                kept_rows[pos] = (unsigned char)lane;
+            }
             if (lane == 0) {
                 kept_bits = kept;
                 kept_total = base + (int)__popcll(kept);
             }
         }
         __syncthreads();
-        const unsigned long long kb = kept_bits;
-        for (int j = blk + 1 + threadIdx.x; j < col_blocks; j += kSweepThreads) {
-            unsigned long long acc = remv[j];
-            unsigned long long rest = kb;
-            while (rest) {
-                const int i = __builtin_ctzll(rest);
-                rest &= rest - 1ull;
-                acc |= mask[(size_t)(blk * 64 + i) * col_blocks + j];
-            }
-            remv[j] = acc;
+        const int nk = (int)__popcll(kept_bits);
+        const int ncols = col_blocks - (blk + 1);  // columns to the right of the tile
+        const int work = nk * ncols;
+        for (int w = threadIdx.x; w < work; w += kSweepThreads) {
+            const int r = w / ncols, j = blk + 1 + (w - r * ncols);
+            const unsigned long long m = mask[(size_t)(blk * 64 + kept_rows[r]) * col_blocks + j];
+            if (m) atomicOr(&remv[j], m);
         }
         __syncthreads();
     }
@@ -303,8 +304,14 @@ static int nms_impl(const float *boxes, int boxes_num, float thresh, void *works
     const int col_blocks = (boxes_num + 63) / 64;
     if (col_blocks > 65535 || (size_t)col_blocks * 8 > 60 * 1024) return EPNET_ELIMIT;
     unsigned long long *mask = (unsigned long long *)workspace;
-    hipLaunchKernelGGL(nms_mask_kernel<ROTATED>, dim3(col_blocks, col_blocks), dim3(64), 0, s, boxes_num, thresh, boxes,
-                       mask);
+    BoxTrig *trig = (BoxTrig *)(mask + (size_t)boxes_num * col_blocks);
+    if (ROTATED) {
+        hipLaunchKernelGGL(box_trig_kernel, dim3(div_up(boxes_num, 256)), dim3(256), 0, s, boxes_num, boxes, trig);
+        int rc0 = check_launch("nms_trig");
+        if (rc0) return rc0;
+    }
+    hipLaunchKernelGGL(nms_mask_kernel<ROTATED>, dim3(div_up(boxes_num, 4), col_blocks), dim3(256), 0, s, boxes_num, thresh,
+                       boxes, trig, mask);
     int rc = check_launch("nms_mask");
     if (rc) return rc;
     hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(kSweepThreads), (size_t)col_blocks * 8, s, boxes_num, mask,
@@ -341,7 +348,7 @@ extern "C" int epnet_boxes_iou_bev(int num_a, const float *boxes_a, int num_b, c
 extern "C" size_t epnet_nms_workspace_bytes(int boxes_num) {
     if (boxes_num <= 0) return 0;
     const size_t col_blocks = ((size_t)boxes_num + 63) / 64;
-    return (size_t)boxes_num * col_blocks * sizeof(unsigned long long);
+    return (size_t)boxes_num * col_blocks * sizeof(unsigned long long) + (size_t)boxes_num * sizeof(BoxTrig);
 }
 
 extern "C" int epnet_nms(const float *boxes, int boxes_num, float thresh, void *workspace, size_t workspace_bytes,

@@ -39,7 +39,7 @@ def test_argument_validation_without_gpu(hiplib):
     assert hiplib.epnet_ball_query(-1, 1, 1, 1.0, 1, None, None, None, None) == -1
     assert hiplib.epnet_furthest_point_sampling(1, 16, 4, None, None, None, None) == -1
     assert hiplib.epnet_group_points(1, 1, 1, 1, 1, None, None, None, None) == -1
-    assert hiplib.epnet_nms_workspace_bytes(6300) == 6300 * 99 * 8
+    assert hiplib.epnet_nms_workspace_bytes(6300) == 6300 * 99 * 8 + 6300 * 16
     assert hiplib.epnet_nms_workspace_bytes(0) == 0
     # empty problems are no-ops
     assert hiplib.epnet_ball_query(0, 10, 10, 1.0, 4, None, None, None, None) == 0
