@@ -376,7 +376,6 @@ __global__ __launch_bounds__(64 * kW) void fps_pruned_kernel(int n, int m, const
                                                              float *__restrict__ temp, int *__restrict__ idxs) {
     typedef float vecf __attribute__((ext_vector_type(PPT)));
     typedef int veci __attribute__((ext_vector_type(PPT)));
-    typedef unsigned vecr __attribute__((ext_vector_type(PPT / 2)));
     constexpr int kT = 64 * kW;
     constexpr int NP = kT * PPT;  // padded point count (power of two)
     extern __shared__ int s_dyn[];  // cell histogram, then NP 16-bit point indices in cell order
@@ -402,9 +401,10 @@ __global__ __launch_bounds__(64 * kW) void fps_pruned_kernel(int n, int m, const
     cell_sort_lds(xyz, n, grid, hist, s_part, perm);
 
     // ---- sorted position p = (group << 6 | lane); group g of 64 sorted points -> (wave g % kW, slot g / kW)
+    // perm[] is turned in place into the table of reference ranks (0xFFFF = padding): entry p is only ever
+    // touched by the thread that owns position p
     vecf x, y, z;
     veci t;
-    vecr rk2;  // reference ranks of this thread's points, two 16-bit values per register (0xFFFF = padding)
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
         const int p = ((j * kW + wave) << 6) | lane;
@@ -420,9 +420,9 @@ __global__ __launch_bounds__(64 * kW) void fps_pruned_kernel(int n, int m, const
             x[j] = y[j] = z[j] = 0.f;
             t[j] = kNeg1;
         }
-        if (j & 1) rk2[j >> 1] |= r16 << 16;
-        else rk2[j >> 1] = r16;
+        perm[p] = (unsigned short)r16;
     }
+    const unsigned short *rank16 = perm;
 
     // ---- bucket summaries
     int bm = kNeg1;
@@ -471,27 +471,31 @@ __global__ __launch_bounds__(64 * kW) void fps_pruned_kernel(int n, int m, const
             bm = (sub == j) ? gm : bm;
         }
         EPNET_STAMP(t2);
-        // C. this wave's maximum; the points that hold it (usually one) compete by reference rank
+        // C. this wave's maximum; the points that hold it (usually exactly one) compete by reference rank
         const int wbest = wave_max_all(bm);
         unsigned cand = fold_parts<PPT>(__ballot(bm == wbest));
         unsigned racc = 0xFFFFFFFFu;
         float xa = 0.f, ya = 0.f, za = 0.f;
+        int holders = 0;
         do {
             const int j = (int)__builtin_ctz(cand);
             cand &= cand - 1u;
-            const unsigned rk = (rk2[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
-            const unsigned r = (t[j] == wbest) ? rk : 0xFFFFFFFFu;
+            const unsigned rk = rank16[((j * kW + wave) << 6) | lane];  // LDS; latency hidden behind the indexed reads
+            const bool eq = t[j] == wbest;
+            holders += (int)__popcll(__ballot(eq));
+            const unsigned r = eq ? rk : 0xFFFFFFFFu;
             const bool take = r < racc;
             racc = take ? r : racc;
             xa = take ? x[j] : xa;
             ya = take ? y[j] : ya;
             za = take ? z[j] : za;
         } while (cand);
-        const unsigned rmin = wave_min_all(racc);
+        // one holder (the rule): that lane publishes; several equal maxima: the smallest rank does
+        const unsigned rmin = holders == 1 ? 0xFFFFFFFEu : wave_min_all(racc);
         const int buf = it & 1;
-        if (racc == rmin) {  // exactly one lane: ranks are unique
+        if (holders == 1 ? racc != 0xFFFFFFFFu : racc == rmin) {
             s_val[buf][wave] = wbest;
-            s_rec[buf][wave] = make_float4(xa, ya, za, __uint_as_float(rmin));
+            s_rec[buf][wave] = make_float4(xa, ya, za, __uint_as_float(racc));
         }
         EPNET_STAMP(t3);
         __syncthreads();
@@ -502,14 +506,15 @@ __global__ __launch_bounds__(64 * kW) void fps_pruned_kernel(int n, int m, const
         const int bmx = period_max<kW>(wv);
         const unsigned r2 = (wv == bmx) ? __float_as_uint(rec.w) : 0xFFFFFFFFu;
         const unsigned r2min = period_min<kW>(r2);
-        const bool win = r2 == r2min;  // one lane per period; spread its record with a masked max
-        cx = __int_as_float(period_max<kW>(win ? __float_as_int(rec.x) : (int)0x80000000));
-        cy = __int_as_float(period_max<kW>(win ? __float_as_int(rec.y) : (int)0x80000000));
-        cz = __int_as_float(period_max<kW>(win ? __float_as_int(rec.z) : (int)0x80000000));
-        if (q == 0) s_idx[it & (kIdxBuf - 1)] = unrank14(r2min);
+        const int wl = (int)__builtin_ctzll(__ballot(r2 == r2min));  // a lane holding the winning record
+        cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rec.x), wl));
+        cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rec.y), wl));
+        cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rec.z), wl));
+        const int wrank = __builtin_amdgcn_readlane((int)r2min, wl);
+        if (wave == 0) s_idx[it & (kIdxBuf - 1)] = wrank;  // all lanes, same word; converted to an index at the flush
         if ((it & (kIdxBuf - 1)) == kIdxBuf - 1 && wave == 0) {
             const int base = it - (kIdxBuf - 1);
-            for (int e = lane; e < kIdxBuf; e += 64) idxs[base + e] = s_idx[e];
+            for (int e = lane; e < kIdxBuf; e += 64) idxs[base + e] = (base + e) ? unrank14((unsigned)s_idx[e]) : 0;
         }
         EPNET_STAMP(t5);
         EPNET_ACC(1, t0, t1); EPNET_ACC(2, t1, t2); EPNET_ACC(3, t2, t3); EPNET_ACC(4, t3, t4); EPNET_ACC(5, t4, t5);
@@ -518,11 +523,11 @@ __global__ __launch_bounds__(64 * kW) void fps_pruned_kernel(int n, int m, const
     EPNET_ACC(6, t_loop0, t_loop1);
     if (wave == 0) {
         const int base = (m - 1) & ~(kIdxBuf - 1);
-        for (int e = lane; base + e < m; e += 64) idxs[base + e] = s_idx[e];
+        for (int e = lane; base + e < m; e += 64) idxs[base + e] = (base + e) ? unrank14((unsigned)s_idx[e]) : 0;
     }
     if (temp) {
         for (int j = 0; j < PPT; ++j) {
-            const unsigned rk = (rk2[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+            const unsigned rk = rank16[((j * kW + wave) << 6) | lane];
             if (rk != 0xFFFFu) temp[unrank14(rk)] = __int_as_float(t[j]);
         }
     }
@@ -629,7 +634,7 @@ extern "C" int epnet_furthest_point_sampling(int b, int n, int m, const float *x
         int waves = n > 8192 ? 8 : 4;
         if (const char *e = getenv("EPNET_FPS_PWAVES")) {
             const int w = atoi(e);
-            if ((w == 4 || w == 8) && div_up(n, 64 * w) <= 32 && div_up(n, 64 * w) >= 1) waves = w;
+            if ((w == 2 || w == 4 || w == 8) && div_up(n, 64 * w) <= 32 && div_up(n, 64 * w) >= 1) waves = w;
         }
         const int ppt_need = div_up(n, 64 * waves);
         const int ppt = ppt_need <= 8 ? 8 : ppt_need <= 16 ? 16 : 32;
@@ -640,6 +645,10 @@ extern "C" int epnet_furthest_point_sampling(int b, int n, int m, const float *x
             if (ppt == 8) EPNET_FPS_PRUNED(8, 8);
             else if (ppt == 16) EPNET_FPS_PRUNED(8, 16);
             else EPNET_FPS_PRUNED(8, 32);
+        } else if (waves == 2) {
+            if (ppt == 8) EPNET_FPS_PRUNED(2, 8);
+            else if (ppt == 16) EPNET_FPS_PRUNED(2, 16);
+            else EPNET_FPS_PRUNED(2, 32);
         } else {
             if (ppt == 8) EPNET_FPS_PRUNED(4, 8);
             else if (ppt == 16) EPNET_FPS_PRUNED(4, 16);
