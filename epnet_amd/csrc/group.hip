@@ -61,6 +61,51 @@ __global__ __launch_bounds__(kGThreads) void gather_rows_scalar_kernel(int c, in
         out[((size_t)bs * c + ci) * p + q] = points[((size_t)bs * c + ci) * n + id];
 }
 
+// LDS-staged gather: a workgroup copies R whole channel rows (R*n floats) of one scene into LDS with
+// coalesced 16-byte loads, then serves a tile of output positions out of LDS -- the random 4-byte reads
+// become ds_read_b32 (bank conflicts cost a few cycles) instead of 64 scattered L1/L2 requests per wave
+// instruction, and the kernel runs at the rate of its 16-byte coalesced stores. Measured on random
+// indices (C=96, N=4096, P=32768, B=64): direct gather 1.9 TB/s, this kernel see profiles/.
+// grid: (tiles, row chunks, scenes); dynamic LDS: R * n floats; p % 4 == 0.
+__global__ __launch_bounds__(kGThreads) void gather_rows_lds_kernel(int c, int n, int p, int rows, int tile,
+                                                                    const float *__restrict__ points,
+                                                                    const int *__restrict__ idx,
+                                                                    float *__restrict__ out) {
+    extern __shared__ float s_rows[];
+    const int bs = blockIdx.z;
+    const int c0 = blockIdx.y * rows;
+    const int nr = min(rows, c - c0);
+    const float *src = points + ((size_t)bs * c + c0) * n;
+    const int total = nr * n;
+    if ((n & 3) == 0 && ((uintptr_t)src & 15) == 0) {
+        const float4 *src4 = reinterpret_cast<const float4 *>(src);
+        float4 *dst4 = reinterpret_cast<float4 *>(s_rows);
+        for (int e = threadIdx.x; e < total / 4; e += kGThreads) dst4[e] = src4[e];
+    } else {
+        for (int e = threadIdx.x; e < total; e += kGThreads) s_rows[e] = src[e];
+    }
+    __syncthreads();
+    const int q_begin = blockIdx.x * tile, q_end = min(p, q_begin + tile);
+    const int *ix = idx + (size_t)bs * p;
+    float *dst_base = out + ((size_t)bs * c + c0) * p;
+    for (int q = q_begin + threadIdx.x * 4; q < q_end; q += kGThreads * 4) {
+        const int4 id = *reinterpret_cast<const int4 *>(ix + q);
+        float *dst = dst_base + q;
+        const float *row = s_rows;
+#pragma unroll 4
+        for (int r = 0; r < nr; ++r) {
+            float4 v;
+            v.x = row[id.x];
+            v.y = row[id.y];
+            v.z = row[id.z];
+            v.w = row[id.w];
+            *reinterpret_cast<float4 *>(dst) = v;
+            row += n;
+            dst += p;
+        }
+    }
+}
+
 // scatter-add with the destination rows held in LDS. dynamic LDS: rows * n floats.
 __global__ __launch_bounds__(kGThreads) void scatter_rows_lds_kernel(int c, int n, int p, int rows,
                                                                      const float *__restrict__ grad_out,
@@ -101,6 +146,27 @@ static int launch_gather_rows(int b, int c, int n, long long p, const float *poi
     if (!(points && idx && out)) return EPNET_EINVAL;
     if (p > 0x7fffffffll || b > 65535 || div_up(c, kGChan) > 65535) return EPNET_ELIMIT;
     const bool vec = (p % 4 == 0) && (((uintptr_t)idx | (uintptr_t)out) % 16 == 0);
+    constexpr int kLdsBudget = 64 * 1024;  // two workgroups per CU
+    if (vec && c >= 8 && (size_t)n * 4 <= kLdsBudget && p >= 2048) {  // few channels (xyz): the rows stay in L2 anyway
+        int rows = kLdsBudget / (n * 4);
+        if (rows > c) rows = c;
+        if (rows > 32) rows = 32;
+        const int chunks = div_up(c, rows);
+        // enough workgroups to fill the chip; every tile re-stages its rows, so keep tiles >= 2048 positions
+        int tiles = div_up(1024, b * chunks);
+        const int max_tiles = (int)(p / 2048);
+        if (tiles > max_tiles) tiles = max_tiles;
+        if (tiles < 1) tiles = 1;
+        int tile = (int)div_up64(p, tiles);
+        tile = (tile + 1023) / 1024 * 1024;  // whole passes of the workgroup (256 threads x 4 positions)
+        tiles = (int)div_up64(p, tile);
+        if (chunks <= 65535) {
+            dim3 grid(tiles, chunks, b);
+            hipLaunchKernelGGL(gather_rows_lds_kernel, grid, dim3(kGThreads), (size_t)rows * n * 4, s, c, n, (int)p, rows, tile,
+                               points, idx, out);
+            return check_launch(what);
+        }
+    }
     if (vec) {
         dim3 grid((unsigned)div_up64(p / 4, kGThreads), div_up(c, kGChan), b);
         hipLaunchKernelGGL(gather_rows_vec4_kernel, grid, dim3(kGThreads), 0, s, c, n, (int)p, points, idx, out);
