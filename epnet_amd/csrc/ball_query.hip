@@ -102,7 +102,7 @@ __global__ __launch_bounds__(kBqThreads) void ball_query_kernel(int n, int m, fl
 
 // ---- indexed path ----------------------------------------------------------------------------------
 //
-// For the big levels (N up to 16384) the scan is N*M pair tests although a ball only ever contains a
+// For the big levels (N from 2048 up to 65536) the scan is N*M pair tests although a ball only ever contains a
 // handful of points. With caller-supplied scratch the query is split in two launches:
 //   bq_index_kernel  one workgroup per scene sorts the points by grid cell (counting sort on an interleaved cell code)
 //                    and writes them, with their ORIGINAL index, as float4 plus one bounding box per
@@ -116,29 +116,54 @@ __global__ __launch_bounds__(kBqThreads) void ball_query_kernel(int n, int m, fl
 // The point test is the same expression as above: d2 = (cx-x)*(cx-x) + (cy-y)*(cy-y) + (cz-z)*(cz-z).
 
 constexpr int kIxThreads = 1024;
-constexpr int kIxMaxPoints = 16384;
+constexpr int kIxMaxPoints = 65536;
 
 __global__ __launch_bounds__(kIxThreads) void bq_index_kernel(int n, int np, const float *__restrict__ xyz,
                                                               float4 *__restrict__ sorted, float *__restrict__ boxes) {
-    extern __shared__ int s_dyn[];  // cell histogram, then np 16-bit indices in cell order
+    extern __shared__ int s_hist[];  // cell histogram / running offsets (spatial.h)
     __shared__ float s_box[6][16];
     __shared__ int s_part[16];
-    int *hist = s_dyn;
-    unsigned short *perm = reinterpret_cast<unsigned short *>(s_dyn + cell_hist_words(kIxThreads));
-    const int q = threadIdx.x, lane = q & 63;
+    const int q = threadIdx.x, lane = q & 63, wave = q >> 6;
     xyz += (size_t)blockIdx.x * n * 3;
     sorted += (size_t)blockIdx.x * np;
     boxes += (size_t)blockIdx.x * (np / 64) * 6;
     float lo[3], ext[3];
     block_bbox3(xyz, n, s_box, lo, ext);
     const CellGrid g = make_cell_grid(lo, ext);
-    cell_sort_lds(xyz, n, g, hist, s_part, perm);
+    // counting sort by cell, scattering the points (with their original index) straight to global memory
+    constexpr int per = kCells / kIxThreads, per_shift = 4;
+    static_assert(per == 16, "scan layout");
+    for (int i = q; i < cell_hist_words(kIxThreads); i += kIxThreads) s_hist[i] = 0;
+    __syncthreads();
+    for (int k = q; k < n; k += kIxThreads)
+        atomicAdd(&s_hist[hist_at((int)cell_code(g, xyz[k * 3 + 0], xyz[k * 3 + 1], xyz[k * 3 + 2]), per_shift)], 1);
+    __syncthreads();
+    int sum = 0;
+    for (int i = 0; i < per; ++i) sum += s_hist[hist_at(q * per + i, per_shift)];
+    const int incl = wave_inclusive_scan(sum);
+    if (lane == 63) s_part[wave] = incl;
+    __syncthreads();
+    int base = incl - sum;
+    for (int w = 0; w < wave; ++w) base += s_part[w];
+    for (int i = 0; i < per; ++i) {
+        const int at = hist_at(q * per + i, per_shift);
+        const int c = s_hist[at];
+        s_hist[at] = base;
+        base += c;
+    }
+    __syncthreads();
+    for (int k = q; k < n; k += kIxThreads) {
+        const float x = xyz[k * 3 + 0], y = xyz[k * 3 + 1], z = xyz[k * 3 + 2];
+        const int pos = atomicAdd(&s_hist[hist_at((int)cell_code(g, x, y, z), per_shift)], 1);
+        sorted[pos] = make_float4(x, y, z, __int_as_float(k));
+    }
+    for (int p = n + q; p < np; p += kIxThreads)  // padding: never inside a ball
+        sorted[p] = make_float4(3.0e38f, 3.0e38f, 3.0e38f, __int_as_float(-1));
+    __threadfence_block();
+    __syncthreads();  // the scattered points are read back by other waves of this workgroup below
     for (int p = q; p < np; p += kIxThreads) {  // one wave handles one bucket at a time
+        const float4 v = sorted[p];
         const bool real = p < n;
-        const int k = real ? (int)perm[p] : 0;
-        float4 v = make_float4(3.0e38f, 3.0e38f, 3.0e38f, __int_as_float(-1));  // padding: never inside a ball
-        if (real) v = make_float4(xyz[k * 3 + 0], xyz[k * 3 + 1], xyz[k * 3 + 2], __int_as_float(k));
-        sorted[p] = v;
         float mn[3] = {real ? v.x : 3.4e38f, real ? v.y : 3.4e38f, real ? v.z : 3.4e38f};
         float mx[3] = {real ? v.x : -3.4e38f, real ? v.y : -3.4e38f, real ? v.z : -3.4e38f};
 #pragma unroll
@@ -205,25 +230,23 @@ __global__ __launch_bounds__(kQThreads) void bq_query_kernel(int np, int m, floa
         }
     }
     // read the bitmap back in index order: lane l owns bits [l*32*DPL, (l+1)*32*DPL)
-    unsigned w[DPL];
     int cnt = 0;
-#pragma unroll
-    for (int i = 0; i < DPL; ++i) {
-        w[i] = bits[lane * DPL + i];
-        cnt += __popc(w[i]);
-    }
+#pragma unroll 8
+    for (int i = 0; i < DPL; ++i) cnt += __popc(bits[lane * DPL + i]);
     const int incl = wave_inclusive_scan(cnt);
     const int total = __builtin_amdgcn_readlane(incl, 63);
     int pos = incl - cnt;
     int mine_first = 0x7fffffff;
-#pragma unroll
-    for (int i = 0; i < DPL; ++i) {
-        unsigned ww = w[i];
-        if (ww && mine_first == 0x7fffffff) mine_first = (lane * DPL + i) * 32 + (int)__builtin_ctz(ww);
-        while (ww && pos < nsample) {
-            const int bit = (int)__builtin_ctz(ww);
-            ww &= ww - 1u;
-            out[pos++] = (lane * DPL + i) * 32 + bit;
+    if (cnt > 0 && (pos < nsample || pos == 0)) {
+        for (int i = 0; i < DPL; ++i) {
+            unsigned ww = bits[lane * DPL + i];
+            if (ww && mine_first == 0x7fffffff) mine_first = (lane * DPL + i) * 32 + (int)__builtin_ctz(ww);
+            while (ww && pos < nsample) {
+                const int bit = (int)__builtin_ctz(ww);
+                ww &= ww - 1u;
+                out[pos++] = (lane * DPL + i) * 32 + bit;
+            }
+            if (pos >= nsample) break;
         }
     }
     // padding with the first hit (ball_query_gpu.cu:35-39); an empty ball is all zeros
@@ -258,7 +281,7 @@ extern "C" int epnet_ball_query(int b, int n, int m, float radius, int nsample, 
     return check_launch("ball_query");
 }
 
-static size_t bq_index_lds(int np) { return (size_t)(kCells + kCells / (kCells / kIxThreads) + 64) * sizeof(int) + (size_t)np * 2; }
+static size_t bq_index_lds(int) { return (size_t)(kCells + kCells / (kCells / kIxThreads) + 64) * sizeof(int); }
 
 static int bq_padded(int n) {
     int np = 2048;
@@ -295,7 +318,9 @@ extern "C" int epnet_ball_query_ws(int b, int n, int m, float radius, int nsampl
         case 1: hipLaunchKernelGGL(bq_query_kernel<1>, grid, dim3(kQThreads), 0, s, np, m, radius2, nsample, new_xyz, sorted, boxes, idx); break;
         case 2: hipLaunchKernelGGL(bq_query_kernel<2>, grid, dim3(kQThreads), 0, s, np, m, radius2, nsample, new_xyz, sorted, boxes, idx); break;
         case 4: hipLaunchKernelGGL(bq_query_kernel<4>, grid, dim3(kQThreads), 0, s, np, m, radius2, nsample, new_xyz, sorted, boxes, idx); break;
-        default: hipLaunchKernelGGL(bq_query_kernel<8>, grid, dim3(kQThreads), 0, s, np, m, radius2, nsample, new_xyz, sorted, boxes, idx); break;
+        case 8: hipLaunchKernelGGL(bq_query_kernel<8>, grid, dim3(kQThreads), 0, s, np, m, radius2, nsample, new_xyz, sorted, boxes, idx); break;
+        case 16: hipLaunchKernelGGL(bq_query_kernel<16>, grid, dim3(kQThreads), 0, s, np, m, radius2, nsample, new_xyz, sorted, boxes, idx); break;
+        default: hipLaunchKernelGGL(bq_query_kernel<32>, grid, dim3(kQThreads), 0, s, np, m, radius2, nsample, new_xyz, sorted, boxes, idx); break;
     }
     return check_launch("ball_query query");
 }

@@ -121,6 +121,7 @@ def test_fps_full_size_properties():
     (16, 512, 128, 0.2, 64, "kitti"), (16, 128, 32, 0.4, 64, "kitti"),   # RCNN stage
     (3, 1000, 77, 1.5, 5, "kitti"), (2, 2100, 9, 3.0, 70, "kitti"), (1, 63, 3, 50.0, 8, "ubox"),
     (1, 5000, 13, 100.0, 128, "ubox"),                                   # every ball saturates at once
+    (1, 65536, 300, 0.5, 64, "kitti"), (1, 40000, 100, 0.8, 48, "kitti"),  # config-5 size: largest indexed path
 ])
 def test_ball_query_matches_oracle(oracle, b, n, m, radius, ns, kind):
     from epnet_amd import pointnet2_utils as p2u
@@ -164,7 +165,7 @@ def test_ball_query_indexed_and_direct_paths_agree(oracle):
         assert l.epnet_ball_query_ws(b, n, m, radius, ns, dc.data_ptr(), dx.data_ptr(), indexed.data_ptr(), ws.data_ptr(), nbytes - 16, stream) == -3  # ENOMEM
         np.testing.assert_array_equal(host(direct), want)
         np.testing.assert_array_equal(host(indexed), want)
-    assert l.epnet_ball_query_workspace_bytes(4, 512, 128) == 0 and l.epnet_ball_query_workspace_bytes(1, 65536, 16384) == 0
+    assert l.epnet_ball_query_workspace_bytes(4, 512, 128) == 0 and l.epnet_ball_query_workspace_bytes(1, 70000, 16384) == 0
 
 
 def test_ball_query_full_size_property():
