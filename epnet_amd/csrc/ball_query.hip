@@ -131,8 +131,9 @@ __global__ __launch_bounds__(kIxThreads) void bq_index_kernel(int n, int np, con
     block_bbox3(xyz, n, s_box, lo, ext);
     const CellGrid g = make_cell_grid(lo, ext);
     // counting sort by cell, scattering the points (with their original index) straight to global memory
-    constexpr int per = kCells / kIxThreads, per_shift = 4;
-    static_assert(per == 16, "scan layout");
+    constexpr int per = kCells / kIxThreads;
+    constexpr int per_shift = per == 16 ? 4 : per == 8 ? 3 : per == 4 ? 2 : -1;
+    static_assert(per_shift > 0, "scan layout");
     for (int i = q; i < cell_hist_words(kIxThreads); i += kIxThreads) s_hist[i] = 0;
     __syncthreads();
     for (int k = q; k < n; k += kIxThreads)
