@@ -150,17 +150,17 @@ def main():
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from epnet_amd import scene_shard
+    rank, local_rank, world = scene_shard.env_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU. EPNET_BENCH_DEVICE / EPNET_BENCH_BACKEND exist only to rehearse the N > 1 code
+    # path on a one-GPU box (all ranks on one device, gloo instead of RCCL)
+    dev_index = int(os.environ.get("EPNET_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        scene_shard.init_process_group(os.environ.get("EPNET_BENCH_BACKEND", "nccl"), device=dev)
 
     from epnet_amd import _lib, pointnet2_cuda as ext, sa_stack, synth
     _lib.lib()  # fail loudly if the HIP library is missing
@@ -168,12 +168,14 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            scene_shard.barrier()
             torch.cuda.synchronize()
 
     def time_stack(batch, steps, warmup):
         """returns (seconds for `steps` steps, the stack, its input)"""
-        xyz = synth.scenes(args.kind, batch, args.points, seed=1 + rank * 100003).to(dev)   # inputs resident in HBM
+        ids = scene_shard.scene_ids(batch * world, rank, world)           # round-robin shard of the global batch
+        fn = {"ubox": synth.ubox_cloud, "kitti": synth.kitti_like_cloud, "dup": synth.dup_cloud}[args.kind]
+        xyz = torch.stack([fn(args.points, scene_shard.scene_seed(1, i)) for i in ids]).to(dev)  # inputs resident in HBM
         stack = sa_stack.SAStack(batch, n=args.points, device=dev, with_fp=args.with_fp, seed=rank,
                                  overlap=not args.no_overlap)
         if args.no_graph:
@@ -191,10 +193,8 @@ def main():
         return time.perf_counter() - t0, stack, xyz
 
     elapsed, stack, xyz = time_stack(args.batch, args.steps, args.warmup)
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    reduce_dev = dev if dist.is_initialized() and dist.get_backend() == "nccl" else "cpu"
+    elapsed = scene_shard.max_over_ranks(elapsed, device=reduce_dev)
     points_per_step = world * args.batch * args.points
     value = points_per_step * args.steps / elapsed
 
