@@ -31,6 +31,8 @@ SIGNATURES = {
     "epnet_group_points": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "epnet_group_points_grad": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "epnet_three_nn": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "epnet_three_nn_workspace_bytes": (_sz, [_i, _i, _i]),
+    "epnet_three_nn_ws": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "epnet_three_interpolate": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "epnet_three_interpolate_grad": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "epnet_boxes_overlap_bev": (_i, [_i, _vp, _i, _vp, _vp, _vp]),

@@ -284,6 +284,13 @@ extern "C" int epnet_ball_query(int b, int n, int m, float radius, int nsample, 
 
 static size_t bq_index_lds(int) { return (size_t)(kCells + kCells / (kCells / kIxThreads) + 64) * sizeof(int); }
 
+// shared with three_nn (interpolate.hip): cell-sorted float4 copy (x, y, z, original index) of n points padded
+// to np (a multiple of 64) per scene, plus one box (6 floats) per 64 sorted points
+int epnet::spatial_index_launch(int b, int n, int np, const float *xyz, float4 *sorted, float *boxes, hipStream_t s) {
+    hipLaunchKernelGGL(bq_index_kernel, dim3(b), dim3(kIxThreads), bq_index_lds(np), s, n, np, xyz, sorted, boxes);
+    return check_launch("spatial index");
+}
+
 static int bq_padded(int n) {
     int np = 2048;
     while (np < n) np <<= 1;
@@ -309,9 +316,7 @@ extern "C" int epnet_ball_query_ws(int b, int n, int m, float radius, int nsampl
     const int np = bq_padded(n);
     float4 *sorted = (float4 *)workspace;
     float *boxes = (float *)(sorted + (size_t)b * np);
-    hipLaunchKernelGGL(bq_index_kernel, dim3(b), dim3(kIxThreads), bq_index_lds(np), s, n, np, xyz,
-                       sorted, boxes);
-    int rc = check_launch("ball_query index");
+    int rc = spatial_index_launch(b, n, np, xyz, sorted, boxes, s);
     if (rc) return rc;
     const float radius2 = radius * radius;  // ball_query_gpu.cu:23
     dim3 grid(div_up(m, kQThreads / 64), b);

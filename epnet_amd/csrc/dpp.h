@@ -1,0 +1,49 @@
+// dpp.h -- wave64 reductions on the vector ALU (DPP row steps + gfx950 row / half swaps): results land in
+// every lane, no LDS (ds_bpermute) and no scalar round trip.
+#pragma once
+#include "common.h"
+
+namespace epnet {
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+
+// max over each row of 16 lanes, result in every lane of the row
+__device__ __forceinline__ int row16_max(int v) {
+    v = max(v, dpp_i32<0xB1>(v));   // quad_perm [1,0,3,2]
+    v = max(v, dpp_i32<0x4E>(v));   // quad_perm [2,3,0,1]
+    v = max(v, dpp_i32<0x124>(v));  // row_ror:4
+    v = max(v, dpp_i32<0x128>(v));  // row_ror:8
+    return v;
+}
+__device__ __forceinline__ unsigned row16_min(unsigned v) {
+    v = min(v, dpp_u32<0xB1>(v));
+    v = min(v, dpp_u32<0x4E>(v));
+    v = min(v, dpp_u32<0x124>(v));
+    v = min(v, dpp_u32<0x128>(v));
+    return v;
+}
+
+__device__ __forceinline__ int wave_max_all(int v) {
+    v = row16_max(v);
+    const auto a = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    v = max((int)a[0], (int)a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    return max((int)b[0], (int)b[1]);
+}
+
+__device__ __forceinline__ unsigned wave_min_all(unsigned v) {
+    v = row16_min(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    v = min(a[0], a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return min(b[0], b[1]);
+}
+
+}  // namespace epnet

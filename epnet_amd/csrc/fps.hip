@@ -31,6 +31,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "dpp.h"
 #include "spatial.h"
 
 // clang exposes no builtin for v_writelane_b32; bind the LLVM intrinsic by name (value, lane, old)
@@ -51,20 +52,6 @@ __device__ __forceinline__ unsigned bitrev_lg(unsigned v, int lg) {
 // value, which is a negative int) signed integer order == float order and bit equality == float
 // equality, and v_min_i32 / v_max3_i32 need none of the NaN-canonicalising v_max the compiler has to
 // put in front of every fminf / fmaxf.
-template <int CTRL>
-__device__ __forceinline__ int dpp_i32(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
-}
-
-// max over each row of 16 lanes, result in every lane of the row
-__device__ __forceinline__ int row16_max(int v) {
-    v = max(v, dpp_i32<0xB1>(v));   // quad_perm [1,0,3,2]
-    v = max(v, dpp_i32<0x4E>(v));   // quad_perm [2,3,0,1]
-    v = max(v, dpp_i32<0x124>(v));  // row_ror:4
-    v = max(v, dpp_i32<0x128>(v));  // row_ror:8
-    return v;
-}
-
 // wave-wide max, returned wave-uniform (scalar registers)
 __device__ __forceinline__ int wave_max_i32(int v) {
     const int r = row16_max(v);
@@ -286,31 +273,6 @@ __device__ unsigned long long g_stats[16];
 
 __device__ __forceinline__ unsigned rank14(int k) { return (bitrev_lg((unsigned)k & 1023u, 10) << 4) | ((unsigned)k >> 10); }
 __device__ __forceinline__ int unrank14(unsigned r) { return (int)(bitrev_lg(r >> 4, 10) + ((r & 15u) << 10)); }
-
-template <int CTRL>
-__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
-    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
-}
-
-// reductions whose result lands in EVERY lane (no scalar round trip)
-__device__ __forceinline__ int wave_max_all(int v) {
-    v = row16_max(v);
-    const auto a = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
-    v = max((int)a[0], (int)a[1]);
-    const auto b = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
-    return max((int)b[0], (int)b[1]);
-}
-
-__device__ __forceinline__ unsigned wave_min_all(unsigned v) {
-    v = min(v, dpp_u32<0xB1>(v));
-    v = min(v, dpp_u32<0x4E>(v));
-    v = min(v, dpp_u32<0x124>(v));
-    v = min(v, dpp_u32<0x128>(v));
-    const auto a = __builtin_amdgcn_permlane16_swap(v, v, false, false);
-    v = min(a[0], a[1]);
-    const auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-    return min(b[0], b[1]);
-}
 
 // max over aligned groups of G lanes (G = 8, 16 or 32), result in every lane of the group
 template <int G>

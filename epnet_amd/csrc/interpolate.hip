@@ -18,6 +18,8 @@
 #include <math.h>
 
 #include "common.h"
+#include "dpp.h"
+#include "spatial.h"
 
 namespace epnet {
 
@@ -114,6 +116,117 @@ __global__ __launch_bounds__(kNnThreads) void three_nn_kernel(int n, int m, cons
     }
 }
 
+// ---- indexed three_nn -------------------------------------------------------------------------------
+// With caller scratch the known points are cell-sorted into buckets of 64 with boxes (the ball-query
+// index, spatial.h). One wave per unknown point u:
+//   1. lane b evaluates the lower bound L_b = |clamp(u, box_b) - u|^2 of bucket b (same fp32 expression as
+//      the point distance, so d >= L_b for every point of the bucket);
+//   2. the bucket with the smallest bound is scanned; the 3rd smallest of its four row minima bounds the
+//      true third-nearest distance from above (four distinct points);
+//   3. every bucket with L_b <= that bound is scanned; each lane keeps the three best (d, k) pairs it saw;
+//   4. three rounds of a 64-bit wave minimum over (bits(d) << 32 | k) pop the global three best.
+// A bucket that is not scanned has L_b > bound >= d3, so it holds neither a closer point nor an equal one:
+// the result is the reference's (strict '<' in index order == lexicographic (d, k)), bit for bit.
+constexpr int kNnIxThreads = 256;
+constexpr int kNnIxMinKnown = 512;
+
+__global__ __launch_bounds__(kNnIxThreads) void three_nn_indexed_kernel(int n, int m, int np,
+                                                                        const float *__restrict__ unknown,
+                                                                        const float4 *__restrict__ sorted,
+                                                                        const float *__restrict__ boxes,
+                                                                        float *__restrict__ dist2, int *__restrict__ idx) {
+    const int lane = threadIdx.x & 63;
+    const int bs = blockIdx.y;
+    const int pt = blockIdx.x * (kNnIxThreads / 64) + (threadIdx.x >> 6);
+    if (pt >= n) return;  // wave-uniform
+    sorted += (size_t)bs * np;
+    boxes += (size_t)bs * (np / 64) * 6;
+    const float *u = unknown + ((size_t)bs * n + pt) * 3;
+    const float ux = u[0], uy = u[1], uz = u[2];
+    const int nb = np >> 6;
+    constexpr unsigned kNone = 0xFFFFFFFFu;  // "no point": above every finite distance's bit pattern
+
+    // per-lane three best (bits(d), k) pairs; d >= +0, so the bit pattern orders like the float
+    unsigned d0 = kNone, d1 = kNone, d2 = kNone;
+    int i0 = 0x7fffffff, i1 = 0x7fffffff, i2 = 0x7fffffff;
+    auto visit = [&](int b) -> unsigned {
+        const float4 p = sorted[(b << 6) + lane];
+        const float dx = ux - p.x, dy = uy - p.y, dz = uz - p.z;
+        const float d = dx * dx + dy * dy + dz * dz;
+        const int k = __float_as_int(p.w);
+        // padding rows (k < 0) and non-finite distances never enter a list, as in the reference (:37-48)
+        const unsigned db = (k >= 0 && d < __builtin_huge_valf()) ? __float_as_uint(d) : kNone;
+        const bool lt0 = db < d0 || (db == d0 && k < i0), lt1 = db < d1 || (db == d1 && k < i1),
+                   lt2 = db < d2 || (db == d2 && k < i2);
+        if (db != kNone) {
+            d2 = lt1 ? d1 : (lt2 ? db : d2);  i2 = lt1 ? i1 : (lt2 ? k : i2);
+            d1 = lt0 ? d0 : (lt1 ? db : d1);  i1 = lt0 ? i0 : (lt1 ? k : i1);
+            d0 = lt0 ? db : d0;               i0 = lt0 ? k : i0;
+        }
+        return db;
+    };
+
+    unsigned bound = kNone;
+    for (int b0 = 0; b0 < nb; b0 += 64) {  // nb <= 64 for m <= 4096: one pass
+        const int b = b0 + lane;
+        unsigned L = kNone;
+        if (b < nb) {
+            const float *bx = boxes + b * 6;
+            const float px = __builtin_amdgcn_fmed3f(ux, bx[0], bx[1]), py = __builtin_amdgcn_fmed3f(uy, bx[2], bx[3]),
+                        pz = __builtin_amdgcn_fmed3f(uz, bx[4], bx[5]);
+            const float dx = ux - px, dy = uy - py, dz = uz - pz;
+            const float Lf = dx * dx + dy * dy + dz * dz;
+            L = Lf < __builtin_huge_valf() ? __float_as_uint(Lf) : kNone;  // all-padding buckets sit at 3e38
+        }
+        unsigned long long done = 0ull;
+        if (b0 == 0) {
+            // seed with the bucket whose box is nearest; its exact third-smallest distance bounds d3 from above
+            const unsigned mn = wave_min_all(L);
+            const int bstart = (int)__builtin_ctzll(__ballot(L == mn));
+            unsigned db = visit(bstart);
+            done = 1ull << bstart;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const unsigned mnr = wave_min_all(db);
+                bound = mnr;
+                const unsigned long long at = __ballot(db == mnr);
+                if (lane == (int)__builtin_ctzll(at)) db = kNone;  // drop one holder of the minimum
+            }
+        }
+        unsigned long long cand = __ballot(b < nb && L <= bound) & ~done;
+        while (cand) {
+            const int bb = b0 + (int)__builtin_ctzll(cand);
+            cand &= cand - 1ull;
+            visit(bb);
+        }
+    }
+    // pop the wave's three smallest (d, k) pairs: min distance, then min index among its holders
+    unsigned bd[3];
+    int bi[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const unsigned md = wave_min_all(d0);
+        const unsigned mk = wave_min_all(d0 == md ? (unsigned)i0 : kNone);
+        bd[r] = md;
+        bi[r] = (int)mk;
+        if (d0 == md && (unsigned)i0 == mk && md != kNone) {  // exactly one lane: indices are unique
+            d0 = d1; i0 = i1;
+            d1 = d2; i1 = i2;
+            d2 = kNone; i2 = 0x7fffffff;
+        }
+    }
+    if (lane == 0) {
+        float *dd = dist2 + ((size_t)bs * n + pt) * 3;
+        int *ii = idx + ((size_t)bs * n + pt) * 3;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const bool have = bd[r] != kNone;
+            dd[r] = have ? __uint_as_float(bd[r]) : __builtin_huge_valf();  // unfilled slot: (float)1e40 = inf, index 0
+            ii[r] = have ? bi[r] : 0;
+        }
+    }
+}
+
 constexpr int kTiThreads = 256;
 constexpr int kTiChan = 16;
 
@@ -149,6 +262,53 @@ __global__ __launch_bounds__(kTiThreads) void three_interpolate_kernel(int c, in
             *reinterpret_cast<float4 *>(dst) = make_float4(r[0], r[1], r[2], r[3]);
         } else {
             for (int u = 0; u < cnt; ++u) dst[u] = r[u];
+        }
+    }
+}
+
+// LDS-staged variant (see gather_rows_lds_kernel in group.hip): R whole rows of `points` (R*m floats) are
+// copied into LDS with coalesced loads; the 3 random reads per output then come from LDS.
+// grid: (tiles, row chunks, scenes); dynamic LDS: rows * m floats; n % 4 == 0.
+__global__ __launch_bounds__(kTiThreads) void three_interpolate_lds_kernel(int c, int m, int n, int rows, int tile,
+                                                                           const float *__restrict__ points,
+                                                                           const int *__restrict__ idx,
+                                                                           const float *__restrict__ weight,
+                                                                           float *__restrict__ out) {
+    extern __shared__ float s_rows[];
+    const int bs = blockIdx.z;
+    const int c0 = blockIdx.y * rows;
+    const int nr = min(rows, c - c0);
+    const float *src = points + ((size_t)bs * c + c0) * m;
+    const int total = nr * m;
+    if ((m & 3) == 0 && ((uintptr_t)src & 15) == 0) {
+        const float4 *src4 = reinterpret_cast<const float4 *>(src);
+        float4 *dst4 = reinterpret_cast<float4 *>(s_rows);
+        for (int e = threadIdx.x; e < total / 4; e += kTiThreads) dst4[e] = src4[e];
+    } else {
+        for (int e = threadIdx.x; e < total; e += kTiThreads) s_rows[e] = src[e];
+    }
+    __syncthreads();
+    const int i_begin = blockIdx.x * tile, i_end = min(n, i_begin + tile);
+    float *dst_base = out + ((size_t)bs * c + c0) * n;
+    for (int i0 = i_begin + threadIdx.x * 4; i0 < i_end; i0 += kTiThreads * 4) {
+        int ix[4][3];
+        float w[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                ix[u][j] = idx[((size_t)bs * n + i0 + u) * 3 + j];
+                w[u][j] = weight[((size_t)bs * n + i0 + u) * 3 + j];
+            }
+        const float *row = s_rows;
+        float *dst = dst_base + i0;
+        for (int r = 0; r < nr; ++r) {
+            float o[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) o[u] = w[u][0] * row[ix[u][0]] + w[u][1] * row[ix[u][1]] + w[u][2] * row[ix[u][2]];
+            *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+            row += m;
+            dst += n;
         }
     }
 }
@@ -220,6 +380,25 @@ extern "C" int epnet_three_interpolate(int b, int c, int m, int n, const float *
     if (b == 0 || c == 0 || n == 0) return EPNET_OK;
     EPNET_REQUIRE(points && idx && weight && out);
     if (b > 65535 || div_up(c, kTiChan) > 65535) return EPNET_ELIMIT;
+    constexpr int kLdsBudget = 64 * 1024;
+    if (c >= 8 && (n % 4) == 0 && n >= 2048 && (size_t)m * 4 <= kLdsBudget && ((uintptr_t)out % 16) == 0) {
+        int rows = kLdsBudget / (m * 4);
+        if (rows > c) rows = c;
+        if (rows > 32) rows = 32;
+        const int chunks = div_up(c, rows);
+        int tiles = div_up(1024, b * chunks);
+        const int max_tiles = n / 2048;
+        if (tiles > max_tiles) tiles = max_tiles;
+        if (tiles < 1) tiles = 1;
+        int tile = div_up(n, tiles);
+        tile = (tile + 1023) / 1024 * 1024;
+        tiles = div_up(n, tile);
+        if (chunks <= 65535) {
+            hipLaunchKernelGGL(three_interpolate_lds_kernel, dim3(tiles, chunks, b), dim3(kTiThreads), (size_t)rows * m * 4,
+                               (hipStream_t)stream, c, m, n, rows, tile, points, idx, weight, out);
+            return check_launch("three_interpolate");
+        }
+    }
     dim3 grid(div_up(div_up(n, 4), kTiThreads), div_up(c, kTiChan), b);
     hipLaunchKernelGGL(three_interpolate_kernel, grid, dim3(kTiThreads), 0, (hipStream_t)stream, c, m, n, points, idx,
                        weight, out);
@@ -248,4 +427,31 @@ extern "C" int epnet_three_interpolate_grad(int b, int c, int n, int m, const fl
                            weight, grad_points);
     }
     return check_launch("three_interpolate_grad");
+}
+
+static int nn_padded(int m) { return (m + 63) / 64 * 64; }
+
+extern "C" size_t epnet_three_nn_workspace_bytes(int b, int n, int m) {
+    if (b <= 0 || n <= 0 || m < kNnIxMinKnown || m > 65536) return 0;  // few known points: the direct scan is used
+    const size_t np = (size_t)nn_padded(m);
+    return (size_t)b * (np * sizeof(float4) + (np / 64) * 6 * sizeof(float));
+}
+
+extern "C" int epnet_three_nn_ws(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx,
+                                 void *workspace, size_t workspace_bytes, epnet_stream_t stream) {
+    const size_t need = epnet_three_nn_workspace_bytes(b, n, m);
+    if (need == 0) return epnet_three_nn(b, n, m, unknown, known, dist2, idx, stream);
+    EPNET_REQUIRE(unknown && known && dist2 && idx && workspace);
+    if (workspace_bytes < need) return EPNET_ENOMEM;
+    if (((uintptr_t)workspace & 15) != 0) return EPNET_EINVAL;
+    EPNET_REQUIRE(b <= 65535);
+    hipStream_t s = (hipStream_t)stream;
+    const int np = nn_padded(m);
+    float4 *sorted = (float4 *)workspace;
+    float *boxes = (float *)(sorted + (size_t)b * np);
+    int rc = spatial_index_launch(b, m, np, known, sorted, boxes, s);
+    if (rc) return rc;
+    dim3 grid(div_up(n, kNnIxThreads / 64), b);
+    hipLaunchKernelGGL(three_nn_indexed_kernel, grid, dim3(kNnIxThreads), 0, s, n, m, np, unknown, sorted, boxes, dist2, idx);
+    return check_launch("three_nn indexed");
 }

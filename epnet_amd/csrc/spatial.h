@@ -193,4 +193,7 @@ __device__ __forceinline__ void cell_sort_lds(const float *__restrict__ xyz, int
     __syncthreads();
 }
 
+// defined in ball_query.hip
+int spatial_index_launch(int b, int n, int np, const float *xyz, float4 *sorted, float *boxes, hipStream_t s);
+
 }  // namespace epnet

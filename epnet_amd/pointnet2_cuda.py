@@ -80,8 +80,14 @@ def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
     pu, pk = dev_ptr(unknown, "unknown", _F), dev_ptr(known, "known", _F)
     pd, pi = dev_ptr(dist2, "dist2", _F), dev_ptr(idx, "idx", _I)
     need(unknown, b * n * 3, "unknown"); need(known, b * m * 3, "known"); need(dist2, b * n * 3, "dist2"); need(idx, b * n * 3, "idx")
+    l = _lib.lib()
+    ws_bytes = l.epnet_three_nn_workspace_bytes(b, n, m)
     with on_device_of(unknown) as s:
-        _lib.check(_lib.lib().epnet_three_nn(b, n, m, pu, pk, pd, pi, s), "three_nn")
+        if ws_bytes:
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=unknown.device)
+            _lib.check(l.epnet_three_nn_ws(b, n, m, pu, pk, pd, pi, ws.data_ptr(), ws_bytes, s), "three_nn")
+        else:
+            _lib.check(l.epnet_three_nn(b, n, m, pu, pk, pd, pi, s), "three_nn")
 
 
 def three_interpolate_wrapper(b, c, m, n, points, idx, weight, out):

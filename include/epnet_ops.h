@@ -97,6 +97,13 @@ int epnet_group_points_grad(int b, int c, int n, int npoints, int nsample, const
 int epnet_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2,
                    int *idx, epnet_stream_t stream);
 
+/* Same result as epnet_three_nn with caller-supplied device scratch (16-byte aligned): the known points are
+ * indexed spatially and each unknown point only visits the buckets that can hold one of its three
+ * nearest; bit-identical output. A workspace size of 0 means the direct scan is used (workspace may be NULL). */
+size_t epnet_three_nn_workspace_bytes(int b, int n, int m);
+int epnet_three_nn_ws(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx,
+                      void *workspace, size_t workspace_bytes, epnet_stream_t stream);
+
 /* three_interpolate_kernel_launcher_fast, interpolate_gpu.cu:99-117 (argument order b,c,m,n).
  * points (B,C,m), idx (B,n,3), weight (B,n,3) -> out (B,C,n) */
 int epnet_three_interpolate(int b, int c, int m, int n, const float *points, const int *idx,

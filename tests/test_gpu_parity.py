@@ -266,7 +266,30 @@ def test_three_nn_ties_and_short_known(oracle):
         np.testing.assert_array_equal(host(d2), o_d2)            # inf in the unfilled slots when m < 3
 
 
-@pytest.mark.parametrize("b,c,m,n", [(2, 256, 64, 256), (2, 128, 1024, 4096), (1, 7, 50, 333), (2, 16, 9, 2)])
+def test_three_nn_indexed_and_direct_paths_agree(oracle):
+    from epnet_amd import _lib
+    l = _lib.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    for b, n, m, kind in ((2, 3000, 1024, "kitti"), (1, 500, 5000, "dup"), (2, 777, 600, "ubox")):
+        unknown = rand_cloud(b, n, seed=61 + n, kind=kind)
+        known = np.ascontiguousarray(rand_cloud(b, m, seed=62 + m, kind=kind))
+        du, dk = dev(unknown), dev(known)
+        o_d2, o_idx = oracle.three_nn(unknown, known)
+        for use_ws in (False, True):
+            d2 = torch.empty((b, n, 3), device=DEV); idx = torch.empty((b, n, 3), dtype=torch.int32, device=DEV)
+            if use_ws:
+                nbytes = l.epnet_three_nn_workspace_bytes(b, n, m)
+                assert nbytes > 0
+                ws = torch.empty((nbytes,), dtype=torch.uint8, device=DEV)
+                assert l.epnet_three_nn_ws(b, n, m, du.data_ptr(), dk.data_ptr(), d2.data_ptr(), idx.data_ptr(), ws.data_ptr(), nbytes, stream) == 0
+            else:
+                assert l.epnet_three_nn(b, n, m, du.data_ptr(), dk.data_ptr(), d2.data_ptr(), idx.data_ptr(), stream) == 0
+            np.testing.assert_array_equal(host(idx), o_idx)
+            np.testing.assert_array_equal(host(d2), o_d2)
+    assert l.epnet_three_nn_workspace_bytes(2, 256, 64) == 0
+
+
+@pytest.mark.parametrize("b,c,m,n", [(2, 256, 64, 256), (2, 128, 1024, 4096), (1, 7, 50, 333), (2, 16, 9, 2), (2, 40, 4096, 16384)])
 def test_three_interpolate_and_grad(oracle, b, c, m, n):
     from epnet_amd import pointnet2_cuda as ext
     rng = np.random.default_rng(c + m)
