@@ -30,6 +30,8 @@ SIGNATURES = {
     "epnet_ball_query_ws": (_i, [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "epnet_group_points": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "epnet_group_points_grad": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "epnet_group_concat": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "epnet_group_concat_grad": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "epnet_three_nn": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "epnet_three_nn_workspace_bytes": (_sz, [_i, _i, _i]),
     "epnet_three_nn_ws": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

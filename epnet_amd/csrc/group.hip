@@ -22,7 +22,9 @@ constexpr int kGThreads = 256;
 constexpr int kGChan = 16;  // channels per workgroup in the forward gather
 
 // vectorised: p % 4 == 0 (so every row of idx/out is 16-B aligned given 16-B aligned bases)
-__global__ __launch_bounds__(kGThreads) void gather_rows_vec4_kernel(int c, int n, int p,
+// `ostride`: elements between consecutive scenes of `out` (c*p for a dense output; larger when the rows land
+// in a channel slice of a wider tensor, see epnet_group_concat)
+__global__ __launch_bounds__(kGThreads) void gather_rows_vec4_kernel(int c, int n, int p, size_t ostride,
                                                                      const float *__restrict__ points,
                                                                      const int *__restrict__ idx,
                                                                      float *__restrict__ out) {
@@ -33,7 +35,7 @@ __global__ __launch_bounds__(kGThreads) void gather_rows_vec4_kernel(int c, int 
     const int4 id = *reinterpret_cast<const int4 *>(idx + (size_t)bs * p + (size_t)q4 * 4);
     const int cend = min(c, c0 + kGChan);
     const float *src = points + ((size_t)bs * c + c0) * n;
-    float *dst = out + ((size_t)bs * c + c0) * p + (size_t)q4 * 4;
+    float *dst = out + (size_t)bs * ostride + (size_t)c0 * p + (size_t)q4 * 4;
 #pragma unroll 4
     for (int ci = c0; ci < cend; ++ci) {
         float4 v;
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(kGThreads) void gather_rows_vec4_kernel(int c, int 
     }
 }
 
-__global__ __launch_bounds__(kGThreads) void gather_rows_scalar_kernel(int c, int n, int p,
+__global__ __launch_bounds__(kGThreads) void gather_rows_scalar_kernel(int c, int n, int p, size_t ostride,
                                                                        const float *__restrict__ points,
                                                                        const int *__restrict__ idx,
                                                                        float *__restrict__ out) {
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(kGThreads) void gather_rows_scalar_kernel(int c, in
     const int id = idx[(size_t)bs * p + q];
     const int cend = min(c, c0 + kGChan);
     for (int ci = c0; ci < cend; ++ci)
-        out[((size_t)bs * c + ci) * p + q] = points[((size_t)bs * c + ci) * n + id];
+        out[(size_t)bs * ostride + (size_t)ci * p + q] = points[((size_t)bs * c + ci) * n + id];
 }
 
 // LDS-staged gather: a workgroup copies R whole channel rows (R*n floats) of one scene into LDS with
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(kGThreads) void gather_rows_scalar_kernel(int c, in
 // instruction, and the kernel runs at the rate of its 16-byte coalesced stores. Measured on random
 // indices (C=96, N=4096, P=32768, B=64): direct gather 1.9 TB/s, this kernel see profiles/.
 // grid: (tiles, row chunks, scenes); dynamic LDS: R * n floats; p % 4 == 0.
-__global__ __launch_bounds__(kGThreads) void gather_rows_lds_kernel(int c, int n, int p, int rows, int tile,
+__global__ __launch_bounds__(kGThreads) void gather_rows_lds_kernel(int c, int n, int p, int rows, int tile, size_t ostride,
                                                                     const float *__restrict__ points,
                                                                     const int *__restrict__ idx,
                                                                     float *__restrict__ out) {
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(kGThreads) void gather_rows_lds_kernel(int c, int n
     __syncthreads();
     const int q_begin = blockIdx.x * tile, q_end = min(p, q_begin + tile);
     const int *ix = idx + (size_t)bs * p;
-    float *dst_base = out + ((size_t)bs * c + c0) * p;
+    float *dst_base = out + (size_t)bs * ostride + (size_t)c0 * p;
     for (int q = q_begin + threadIdx.x * 4; q < q_end; q += kGThreads * 4) {
         const int4 id = *reinterpret_cast<const int4 *>(ix + q);
         float *dst = dst_base + q;
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(kGThreads) void gather_rows_lds_kernel(int c, int n
 }
 
 // scatter-add with the destination rows held in LDS. dynamic LDS: rows * n floats.
-__global__ __launch_bounds__(kGThreads) void scatter_rows_lds_kernel(int c, int n, int p, int rows,
+__global__ __launch_bounds__(kGThreads) void scatter_rows_lds_kernel(int c, int n, int p, int rows, size_t gstride,
                                                                      const float *__restrict__ grad_out,
                                                                      const int *__restrict__ idx,
                                                                      float *__restrict__ grad_points) {
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(kGThreads) void scatter_rows_lds_kernel(int c, int 
     for (int e = threadIdx.x; e < nr * n; e += kGThreads) acc[e] = 0.f;
     __syncthreads();
     const int *ix = idx + (size_t)bs * p;
-    const float *go = grad_out + ((size_t)bs * c + c0) * p;
+    const float *go = grad_out + (size_t)bs * gstride + (size_t)c0 * p;
     for (int q = threadIdx.x; q < p; q += kGThreads) {
         const int id = ix[q];
         for (int r = 0; r < nr; ++r) atomicAdd(&acc[r * n + id], go[(size_t)r * p + q]);
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(kGThreads) void scatter_rows_lds_kernel(int c, int 
 }
 
 // fallback for rows that do not fit LDS: global float atomics, as the reference does
-__global__ __launch_bounds__(kGThreads) void scatter_rows_atomic_kernel(int c, int n, int p,
+__global__ __launch_bounds__(kGThreads) void scatter_rows_atomic_kernel(int c, int n, int p, size_t gstride,
                                                                         const float *__restrict__ grad_out,
                                                                         const int *__restrict__ idx,
                                                                         float *__restrict__ grad_points) {
@@ -137,11 +139,32 @@ __global__ __launch_bounds__(kGThreads) void scatter_rows_atomic_kernel(int c, i
     const int q = blockIdx.x * kGThreads + threadIdx.x;
     if (q >= p) return;
     atomicAdd(grad_points + ((size_t)bs * c + ci) * n + idx[(size_t)bs * p + q],
-              grad_out[((size_t)bs * c + ci) * p + q]);
+              grad_out[(size_t)bs * gstride + (size_t)ci * p + q]);
+}
+
+// grouped, centre-relative coordinates straight from the (B,N,3) layout:
+// out[b, ch, i, s] = xyz[b, idx[b,i,s], ch] - new_xyz[b, i, ch], ch = 0..2  (pointnet2_utils.py:250-252)
+__global__ __launch_bounds__(kGThreads) void group_xyz_centred_kernel(int n, int npoints, int nsample, size_t ostride,
+                                                                      const float *__restrict__ xyz,
+                                                                      const float *__restrict__ new_xyz,
+                                                                      const int *__restrict__ idx, float *__restrict__ out) {
+    const int bs = blockIdx.y;
+    const int p = npoints * nsample;
+    const int q = blockIdx.x * kGThreads + threadIdx.x;
+    if (q >= p) return;
+    const int id = idx[(size_t)bs * p + q];
+    const int ci = q / nsample;
+    const float *pt = xyz + ((size_t)bs * n + id) * 3;
+    const float *ce = new_xyz + ((size_t)bs * npoints + ci) * 3;
+    float *dst = out + (size_t)bs * ostride + q;
+    dst[0] = pt[0] - ce[0];
+    dst[(size_t)p] = pt[1] - ce[1];
+    dst[(size_t)p * 2] = pt[2] - ce[2];
 }
 
 static int launch_gather_rows(int b, int c, int n, long long p, const float *points, const int *idx, float *out,
-                              hipStream_t s, const char *what) {
+                              hipStream_t s, const char *what, size_t ostride = 0) {
+    if (ostride == 0) ostride = (size_t)c * (size_t)p;
     if (b == 0 || c == 0 || p == 0) return EPNET_OK;
     if (!(points && idx && out)) return EPNET_EINVAL;
     if (p > 0x7fffffffll || b > 65535 || div_up(c, kGChan) > 65535) return EPNET_ELIMIT;
@@ -163,22 +186,23 @@ static int launch_gather_rows(int b, int c, int n, long long p, const float *poi
         if (chunks <= 65535) {
             dim3 grid(tiles, chunks, b);
             hipLaunchKernelGGL(gather_rows_lds_kernel, grid, dim3(kGThreads), (size_t)rows * n * 4, s, c, n, (int)p, rows, tile,
-                               points, idx, out);
+                               ostride, points, idx, out);
             return check_launch(what);
         }
     }
     if (vec) {
         dim3 grid((unsigned)div_up64(p / 4, kGThreads), div_up(c, kGChan), b);
-        hipLaunchKernelGGL(gather_rows_vec4_kernel, grid, dim3(kGThreads), 0, s, c, n, (int)p, points, idx, out);
+        hipLaunchKernelGGL(gather_rows_vec4_kernel, grid, dim3(kGThreads), 0, s, c, n, (int)p, ostride, points, idx, out);
     } else {
         dim3 grid((unsigned)div_up64(p, kGThreads), div_up(c, kGChan), b);
-        hipLaunchKernelGGL(gather_rows_scalar_kernel, grid, dim3(kGThreads), 0, s, c, n, (int)p, points, idx, out);
+        hipLaunchKernelGGL(gather_rows_scalar_kernel, grid, dim3(kGThreads), 0, s, c, n, (int)p, ostride, points, idx, out);
     }
     return check_launch(what);
 }
 
 static int launch_scatter_rows(int b, int c, int n, long long p, const float *grad_out, const int *idx,
-                               float *grad_points, hipStream_t s, const char *what) {
+                               float *grad_points, hipStream_t s, const char *what, size_t gstride = 0) {
+    if (gstride == 0) gstride = (size_t)c * (size_t)p;
     if (b == 0 || c == 0 || p == 0 || n == 0) return EPNET_OK;
     if (!(grad_out && idx && grad_points)) return EPNET_EINVAL;
     if (p > 0x7fffffffll || b > 65535) return EPNET_ELIMIT;
@@ -188,12 +212,12 @@ static int launch_scatter_rows(int b, int c, int n, long long p, const float *gr
         if (rows > 8) rows = 8;
         if (rows > c) rows = c;
         dim3 grid(div_up(c, rows), b);
-        hipLaunchKernelGGL(scatter_rows_lds_kernel, grid, dim3(kGThreads), (size_t)rows * n * 4, s, c, n, (int)p, rows,
+        hipLaunchKernelGGL(scatter_rows_lds_kernel, grid, dim3(kGThreads), (size_t)rows * n * 4, s, c, n, (int)p, rows, gstride,
                            grad_out, idx, grad_points);
     } else {
         if (c > 65535) return EPNET_ELIMIT;
         dim3 grid((unsigned)div_up64(p, kGThreads), c, b);
-        hipLaunchKernelGGL(scatter_rows_atomic_kernel, grid, dim3(kGThreads), 0, s, c, n, (int)p, grad_out, idx,
+        hipLaunchKernelGGL(scatter_rows_atomic_kernel, grid, dim3(kGThreads), 0, s, c, n, (int)p, gstride, grad_out, idx,
                            grad_points);
     }
     return check_launch(what);
@@ -227,4 +251,36 @@ extern "C" int epnet_group_points_grad(int b, int c, int n, int npoints, int nsa
     EPNET_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0 && nsample >= 0);
     return launch_scatter_rows(b, c, n, (long long)npoints * nsample, grad_out, idx, grad_points, (hipStream_t)stream,
                                "group_points_grad");
+}
+
+extern "C" int epnet_group_concat(int b, int c, int n, int npoints, int nsample, const float *xyz, const float *new_xyz,
+                                  const float *features, const int *idx, float *out, int use_xyz, epnet_stream_t stream) {
+    EPNET_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0 && nsample >= 0);
+    EPNET_REQUIRE(use_xyz || c > 0);
+    const long long p = (long long)npoints * nsample;
+    if (b == 0 || p == 0) return EPNET_OK;
+    EPNET_REQUIRE(idx && out && (c == 0 || features) && (!use_xyz || (xyz && new_xyz)));
+    if (p > 0x7fffffffll || b > 65535) return EPNET_ELIMIT;
+    hipStream_t s = (hipStream_t)stream;
+    const int ch0 = use_xyz ? 3 : 0;
+    const size_t ostride = (size_t)(ch0 + c) * (size_t)p;
+    if (use_xyz) {
+        hipLaunchKernelGGL(group_xyz_centred_kernel, dim3((unsigned)div_up64(p, kGThreads), b), dim3(kGThreads), 0, s, n, npoints,
+                           nsample, ostride, xyz, new_xyz, idx, out);
+        int rc = check_launch("group_concat xyz");
+        if (rc) return rc;
+    }
+    if (c == 0) return EPNET_OK;
+    return launch_gather_rows(b, c, n, p, features, idx, out + (size_t)ch0 * p, s, "group_concat features", ostride);
+}
+
+extern "C" int epnet_group_concat_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out, const int *idx,
+                                       float *grad_features, int use_xyz, epnet_stream_t stream) {
+    EPNET_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0 && nsample >= 0);
+    const long long p = (long long)npoints * nsample;
+    if (b == 0 || c == 0 || p == 0) return EPNET_OK;
+    const int ch0 = use_xyz ? 3 : 0;
+    const size_t gstride = (size_t)(ch0 + c) * (size_t)p;
+    return launch_scatter_rows(b, c, n, p, grad_out + (size_t)ch0 * p, idx, grad_features, (hipStream_t)stream,
+                               "group_concat_grad", gstride);
 }

@@ -107,3 +107,31 @@ def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_point
     need(grad_points, b * c * m, "grad_points")
     with on_device_of(grad_out) as s:
         _lib.check(_lib.lib().epnet_three_interpolate_grad(b, c, n, m, pg, pi, pw, pp, s), "three_interpolate_grad")
+
+
+# ---- beyond the reference's nine entry points: fused QueryAndGroup tail -----------------
+
+def group_concat_wrapper(b, c, n, npoints, nsample, xyz, new_xyz, features, idx, out, use_xyz):
+    """out (B, 3+C | C, M, ns) = [grouped xyz - centre ; grouped features]; features may be None when c == 0"""
+    px = dev_ptr(xyz, "xyz", _F) if use_xyz else None
+    pn = dev_ptr(new_xyz, "new_xyz", _F) if use_xyz else None
+    pf = dev_ptr(features, "features", _F) if c else None
+    pi, po = dev_ptr(idx, "idx", _I), dev_ptr(out, "out", _F)
+    need(idx, b * npoints * nsample, "idx"); need(out, b * ((3 if use_xyz else 0) + c) * npoints * nsample, "out")
+    if use_xyz:
+        need(xyz, b * n * 3, "xyz"); need(new_xyz, b * npoints * 3, "new_xyz")
+    if c:
+        need(features, b * c * n, "features")
+    with on_device_of(idx) as s:
+        _lib.check(_lib.lib().epnet_group_concat(b, c, n, npoints, nsample, px, pn, pf, pi, po, int(bool(use_xyz)), s),
+                   "group_concat")
+    return 1
+
+
+def group_concat_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_features, use_xyz):
+    pg, pi, pp = dev_ptr(grad_out, "grad_out", _F), dev_ptr(idx, "idx", _I), dev_ptr(grad_features, "grad_features", _F)
+    need(grad_out, b * ((3 if use_xyz else 0) + c) * npoints * nsample, "grad_out"); need(grad_features, b * c * n, "grad_features")
+    with on_device_of(grad_out) as s:
+        _lib.check(_lib.lib().epnet_group_concat_grad(b, c, n, npoints, nsample, pg, pi, pp, int(bool(use_xyz)), s),
+                   "group_concat_grad")
+    return 1

@@ -168,9 +168,36 @@ class BallQuery(Function):
 ball_query = BallQuery.apply
 
 
+class _GroupConcat(Function):
+    """fused tail of QueryAndGroup: [grouped xyz - centre ; grouped features] written once into one tensor
+    (the reference composes two grouping ops, an in-place subtraction and a torch.cat copy)"""
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, features, idx, use_xyz):
+        batch, npoint, nsample = idx.shape
+        n = xyz.shape[1]
+        channels = 0 if features is None else features.shape[1]
+        out = _new(xyz, (batch, (3 if use_xyz else 0) + channels, npoint, nsample))
+        _ext.group_concat_wrapper(batch, channels, n, npoint, nsample, xyz, new_xyz, features, idx, out, use_xyz)
+        ctx.for_backwards = (idx, channels, n, use_xyz)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, channels, n, use_xyz = ctx.for_backwards
+        if channels == 0:
+            return None, None, None, None, None
+        batch, _, npoint, nsample = grad_out.shape
+        grad_features = _new(grad_out, (batch, channels, n), zero=True)
+        _ext.group_concat_grad_wrapper(batch, channels, n, npoint, nsample, grad_out.detach().contiguous(), idx,
+                                       grad_features, use_xyz)
+        return None, None, grad_features, None, None
+
+
 class QueryAndGroup(nn.Module):
     """ball_query -> group xyz -> subtract the centre -> group features -> concat [xyz(3), features(C)].
-    reference: pointnet2_utils.py:231-264"""
+    reference: pointnet2_utils.py:231-264. Same values as that composition; the grouped tensor is produced
+    by one fused op unless a gradient w.r.t. the coordinates is required."""
 
     def __init__(self, radius: float, nsample: int, use_xyz: bool = True):
         super().__init__()
@@ -178,10 +205,17 @@ class QueryAndGroup(nn.Module):
 
     def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: Optional[torch.Tensor] = None):
         idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
+        if features is None:
+            assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
+        coords_need_grad = torch.is_grad_enabled() and (xyz.requires_grad or new_xyz.requires_grad)
+        if not coords_need_grad:
+            feats = None if features is None else features.contiguous()
+            return _GroupConcat.apply(xyz.contiguous(), new_xyz.contiguous(), feats, idx,
+                                      self.use_xyz or features is None)
+        # unfused composition, differentiable w.r.t. the coordinates exactly like the reference
         local_xyz = grouping_operation(xyz.transpose(1, 2).contiguous(), idx)  # (B,3,npoint,nsample)
         local_xyz -= new_xyz.transpose(1, 2).unsqueeze(-1)
         if features is None:
-            assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
             return local_xyz
         grouped = grouping_operation(features, idx)
         return torch.cat([local_xyz, grouped], dim=1) if self.use_xyz else grouped

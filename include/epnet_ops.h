@@ -92,6 +92,19 @@ int epnet_group_points(int b, int c, int n, int npoints, int nsample, const floa
 int epnet_group_points_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out,
                             const int *idx, float *grad_points, epnet_stream_t stream);
 
+/* Fused tail of QueryAndGroup.forward (pointnet2_utils.py:250-257): one call writes
+ *   out (B, 3+C, M, ns) = [ xyz[b, idx[b,i,s], :] - new_xyz[b,i,:]   (3 channels, if use_xyz)
+ *                           features[b, :, idx[b,i,s]]               (C channels) ]
+ * reading xyz in its (B,N,3) layout -- no transposed copy of xyz, no separate centre-subtraction pass over the
+ * grouped tensor and no torch.cat copy of it. features may be NULL when c == 0. Values are bit-identical to the
+ * reference composition (a gather and one fp32 subtraction). */
+int epnet_group_concat(int b, int c, int n, int npoints, int nsample, const float *xyz, const float *new_xyz,
+                       const float *features, const int *idx, float *out, int use_xyz, epnet_stream_t stream);
+
+/* gradient of the above w.r.t. features: grad_out (B, 3+C | C, M, ns) -> grad_features (B,C,N) accumulated into */
+int epnet_group_concat_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out, const int *idx,
+                            float *grad_features, int use_xyz, epnet_stream_t stream);
+
 /* three_nn_kernel_launcher_fast, interpolate_gpu.cu:55-74.
  * unknown (B,n,3), known (B,m,3) -> dist2 (B,n,3) f32 squared distances, idx (B,n,3) i32 */
 int epnet_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2,

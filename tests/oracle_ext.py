@@ -60,7 +60,22 @@ def make_modules():
     def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_points):
         wr(grad_points, _np(grad_points) + oracle.three_interpolate_grad(_np(grad_out), _np(idx), _np(weight), m))
 
-    for f in (ball_query_wrapper, group_points_wrapper, group_points_grad_wrapper, gather_points_wrapper,
+    def group_concat_wrapper(b, c, n, npoints, nsample, xyz, new_xyz, features, idx, out, use_xyz):
+        parts = []
+        if use_xyz:
+            g = oracle.group_points(np.ascontiguousarray(_np(xyz).transpose(0, 2, 1)), _np(idx))
+            parts.append(g - _np(new_xyz).transpose(0, 2, 1)[..., None])
+        if c:
+            parts.append(oracle.group_points(_np(features), _np(idx)))
+        wr(out, np.concatenate(parts, axis=1))
+        return 1
+
+    def group_concat_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_features, use_xyz):
+        g = _np(grad_out)[:, (3 if use_xyz else 0):]
+        wr(grad_features, _np(grad_features) + oracle.group_points_grad(np.ascontiguousarray(g), _np(idx), n))
+        return 1
+
+    for f in (group_concat_wrapper, group_concat_grad_wrapper, ball_query_wrapper, group_points_wrapper, group_points_grad_wrapper, gather_points_wrapper,
               gather_points_grad_wrapper, furthest_point_sampling_wrapper, three_nn_wrapper,
               three_interpolate_wrapper, three_interpolate_grad_wrapper):
         setattr(p2, f.__name__, f)

@@ -437,6 +437,41 @@ def test_sa_and_fp_modules_on_gpu():
     np.testing.assert_allclose(host(out), fp["out"], rtol=0, atol=1e-5)
 
 
+def test_query_and_group_fused_equals_reference_composition():
+    """epnet_group_concat (one fused op) vs the reference's composition of grouping ops, subtraction and cat
+    (pointnet2_utils.py:249-257): identical values, forward; gradients w.r.t. features to 1e-5"""
+    from epnet_amd import pointnet2_utils as p2u
+    xyz = dev(rand_cloud(2, 4096, seed=77, kind="kitti"))
+    new_xyz = xyz[:, ::4].contiguous()
+    g = torch.Generator().manual_seed(5)
+    feats = torch.randn((2, 19, 4096), generator=g).to(DEV)
+    up = torch.randn((2, 22, 1024, 16), generator=g).to(DEV)
+    for use_xyz, with_feats in ((True, True), (False, True), (True, False)):
+        f1 = feats.clone().requires_grad_(True) if with_feats else None
+        fused = p2u.QueryAndGroup(0.8, 16, use_xyz=use_xyz)(xyz, new_xyz, f1)
+        idx = p2u.ball_query(0.8, 16, xyz, new_xyz)
+        f2 = feats.clone().requires_grad_(True) if with_feats else None
+        parts = []
+        if use_xyz or not with_feats:
+            gx = p2u.grouping_operation(xyz.transpose(1, 2).contiguous(), idx)
+            gx -= new_xyz.transpose(1, 2).unsqueeze(-1)
+            parts.append(gx)
+        if with_feats:
+            parts.append(p2u.grouping_operation(f2, idx))
+        ref = torch.cat(parts, dim=1)
+        assert torch.equal(fused, ref)
+        if with_feats:
+            w = up[:, :fused.shape[1]]
+            (fused * w).sum().backward()
+            (ref * w).sum().backward()
+            np.testing.assert_allclose(host(f1.grad), host(f2.grad), rtol=1e-5, atol=1e-5)
+    # a gradient w.r.t. the coordinates takes the unfused, fully differentiable path
+    xr = xyz.clone().requires_grad_(True)
+    out = p2u.QueryAndGroup(0.8, 16)(xr, new_xyz, feats)
+    out.sum().backward()
+    assert xr.grad is not None and torch.isfinite(xr.grad).all()
+
+
 def test_autograd_on_gpu():
     from epnet_amd import pointnet2_utils as p2u
     fx = golden("grads.npz")
