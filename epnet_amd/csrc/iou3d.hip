@@ -192,6 +192,60 @@ __global__ __launch_bounds__(256) void pairwise_bev_kernel(int num_a, const floa
     ans[(size_t)a_idx * num_b + b_idx] = IOU ? iou_bev(ba, bb, ta, tb) : box_overlap(ba, bb, ta, tb);
 }
 
+// ---- fused 3-D IoU (boxes_iou3d_gpu of lib/utils/iou3d/iou3d_utils.py:21-53 in ONE launch) -------------
+// The reference builds the BEV boxes (kitti_utils.boxes3d_to_bev_torch :137-150), calls the overlap kernel and
+// finishes with ~10 small torch kernels (height overlap, volumes, clamp, divide). Every step is an fp32
+// elementwise op, reproduced here in the same order, so the values equal that composition.
+// boxes: (.,7) [x, y, z, h, w, l, ry], y = bottom centre, camera coordinates.
+__device__ __forceinline__ void bev_of(const float *b7, float *bev) {
+    const float half_l = b7[5] / 2, half_w = b7[4] / 2;
+    bev[0] = b7[0] - half_l;
+    bev[1] = b7[2] - half_w;
+    bev[2] = b7[0] + half_l;
+    bev[3] = b7[2] + half_w;
+    bev[4] = b7[6];
+}
+
+__device__ __forceinline__ float iou3d_pair(const float *a7, const float *b7) {
+    float ba[5], bb[5];
+    bev_of(a7, ba);
+    bev_of(b7, bb);
+    const float overlaps_bev = box_overlap(ba, bb, box_trig(ba[4]), box_trig(bb[4]));
+    const float a_min = a7[1] - a7[3], a_max = a7[1], b_min = b7[1] - b7[3], b_max = b7[1];
+    const float max_of_min = fmaxf(a_min, b_min), min_of_max = fminf(a_max, b_max);
+    const float overlaps_h = fmaxf(min_of_max - max_of_min, 0.f);
+    const float overlaps_3d = overlaps_bev * overlaps_h;
+    const float vol_a = a7[3] * a7[4] * a7[5], vol_b = b7[3] * b7[4] * b7[5];
+    return overlaps_3d / fmaxf(vol_a + vol_b - overlaps_3d, 1e-7f);
+}
+
+__global__ __launch_bounds__(256) void iou3d_matrix_kernel(int num_a, const float *__restrict__ boxes_a, int num_b,
+                                                           const float *__restrict__ boxes_b, float *__restrict__ ans) {
+    const int b_idx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int a_idx = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (a_idx >= num_a || b_idx >= num_b) return;
+    float a7[7], b7[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        a7[i] = boxes_a[a_idx * 7 + i];
+        b7[i] = boxes_b[b_idx * 7 + i];
+    }
+    ans[(size_t)a_idx * num_b + b_idx] = iou3d_pair(a7, b7);
+}
+
+__global__ __launch_bounds__(256) void iou3d_pairs_kernel(int k, const float *__restrict__ boxes_a,
+                                                          const float *__restrict__ boxes_b, float *__restrict__ ans) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= k) return;
+    float a7[7], b7[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        a7[j] = boxes_a[i * 7 + j];
+        b7[j] = boxes_b[i * 7 + j];
+    }
+    ans[i] = iou3d_pair(a7, b7);
+}
+
 // per-box trigonometry, once per box instead of once per pair
 __global__ __launch_bounds__(256) void box_trig_kernel(int n, const float *__restrict__ boxes, BoxTrig *__restrict__ trig) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -359,4 +413,24 @@ extern "C" int epnet_nms(const float *boxes, int boxes_num, float thresh, void *
 extern "C" int epnet_nms_normal(const float *boxes, int boxes_num, float thresh, void *workspace,
                                 size_t workspace_bytes, int64_t *keep, int *num_keep, epnet_stream_t stream) {
     return nms_impl<false>(boxes, boxes_num, thresh, workspace, workspace_bytes, keep, num_keep, (hipStream_t)stream);
+}
+
+extern "C" int epnet_boxes_iou3d(int num_a, const float *boxes_a, int num_b, const float *boxes_b, float *ans,
+                                 epnet_stream_t stream) {
+    EPNET_REQUIRE(num_a >= 0 && num_b >= 0);
+    if (num_a == 0 || num_b == 0) return EPNET_OK;
+    EPNET_REQUIRE(boxes_a && boxes_b && ans);
+    if (div_up(num_a, 4) > 65535) return EPNET_ELIMIT;
+    hipLaunchKernelGGL(iou3d_matrix_kernel, dim3(div_up(num_b, 64), div_up(num_a, 4)), dim3(256), 0, (hipStream_t)stream,
+                       num_a, boxes_a, num_b, boxes_b, ans);
+    return check_launch("boxes_iou3d");
+}
+
+extern "C" int epnet_boxes_iou3d_pairs(int k, const float *boxes_a, const float *boxes_b, float *ans,
+                                       epnet_stream_t stream) {
+    EPNET_REQUIRE(k >= 0);
+    if (k == 0) return EPNET_OK;
+    EPNET_REQUIRE(boxes_a && boxes_b && ans);
+    hipLaunchKernelGGL(iou3d_pairs_kernel, dim3(div_up(k, 256)), dim3(256), 0, (hipStream_t)stream, k, boxes_a, boxes_b, ans);
+    return check_launch("boxes_iou3d_pairs");
 }

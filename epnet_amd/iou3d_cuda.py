@@ -33,6 +33,26 @@ def boxes_iou_bev_gpu(boxes_a, boxes_b, ans_iou):
     return _pairwise("epnet_boxes_iou_bev", boxes_a, boxes_b, ans_iou)
 
 
+def boxes_iou3d_fused_gpu(boxes_a, boxes_b, ans_iou3d):
+    """(N,7) x (M,7) -> (N,M) 3-D IoU in one launch (not in the reference extension; see epnet_ops.h)"""
+    pa, pb, po = dev_ptr(boxes_a, "boxes_a", _F), dev_ptr(boxes_b, "boxes_b", _F), dev_ptr(ans_iou3d, "ans", _F)
+    na, nb = boxes_a.size(0), boxes_b.size(0)
+    need(boxes_a, na * 7, "boxes_a"); need(boxes_b, nb * 7, "boxes_b"); need(ans_iou3d, na * nb, "ans")
+    with on_device_of(boxes_a) as s:
+        _lib.check(_lib.lib().epnet_boxes_iou3d(na, pa, nb, pb, po, s), "boxes_iou3d")
+    return 1
+
+
+def boxes_iou3d_pairs_gpu(boxes_a, boxes_b, ans_iou3d):
+    """(K,7), (K,7) -> (K,) 3-D IoU of corresponding pairs in one launch"""
+    pa, pb, po = dev_ptr(boxes_a, "boxes_a", _F), dev_ptr(boxes_b, "boxes_b", _F), dev_ptr(ans_iou3d, "ans", _F)
+    k = boxes_a.size(0)
+    need(boxes_a, k * 7, "boxes_a"); need(boxes_b, k * 7, "boxes_b"); need(ans_iou3d, k, "ans")
+    with on_device_of(boxes_a) as s:
+        _lib.check(_lib.lib().epnet_boxes_iou3d_pairs(k, pa, pb, po, s), "boxes_iou3d_pairs")
+    return 1
+
+
 def _nms_device(fn_name, boxes, thresh):
     """returns (keep_dev int64 (N,), num_keep_dev int32 (1,)), both on the boxes' device, no sync"""
     pb = dev_ptr(boxes, "boxes", _F)

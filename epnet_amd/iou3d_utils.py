@@ -19,17 +19,31 @@ def boxes_iou_bev(boxes_a, boxes_b):
 
 def boxes_iou3d_gpu(boxes_a, boxes_b):
     """boxes_a (N,7), boxes_b (M,7) [x,y,z,h,w,l,ry] (y = bottom centre, camera coords) -> 3-D IoU (N,M):
-    rotated BEV overlap x height overlap over the union volume (clamped at 1e-7)"""
+    rotated BEV overlap x height overlap over the union volume (clamped at 1e-7). One fused launch; the
+    reference composes boxes3d_to_bev_torch, the overlap kernel and ~10 elementwise torch ops (:21-53)."""
+    ans = torch.empty((boxes_a.shape[0], boxes_b.shape[0]), dtype=torch.float32, device=boxes_a.device)
+    iou3d_cuda.boxes_iou3d_fused_gpu(boxes_a.float().contiguous(), boxes_b.float().contiguous(), ans)
+    return ans
+
+
+def boxes_iou3d_pairs_gpu(boxes_a, boxes_b):
+    """boxes_a (K,7), boxes_b (K,7) -> (K,) 3-D IoU of pair i = (a_i, b_i) in one launch -- the batched form of
+    the single-pair calls in lib/rpn/proposal_target_layer.py:239 (not part of the reference's surface)"""
+    ans = torch.empty((boxes_a.shape[0],), dtype=torch.float32, device=boxes_a.device)
+    iou3d_cuda.boxes_iou3d_pairs_gpu(boxes_a.float().contiguous(), boxes_b.float().contiguous(), ans)
+    return ans
+
+
+def boxes_iou3d_composed(boxes_a, boxes_b):
+    """the reference's composition (BEV overlap kernel + torch height/volume math), kept for cross-checks"""
     bev_a = kitti_utils.boxes3d_to_bev_torch(boxes_a)
     bev_b = kitti_utils.boxes3d_to_bev_torch(boxes_b)
     overlaps_bev = torch.zeros((boxes_a.shape[0], boxes_b.shape[0]), dtype=torch.float32, device=boxes_a.device)
     iou3d_cuda.boxes_overlap_bev_gpu(bev_a.contiguous(), bev_b.contiguous(), overlaps_bev)
-
     # y points down: a box spans [y - h, y]
     a_top, a_bottom = (boxes_a[:, 1] - boxes_a[:, 3]).view(-1, 1), boxes_a[:, 1].view(-1, 1)
     b_top, b_bottom = (boxes_b[:, 1] - boxes_b[:, 3]).view(1, -1), boxes_b[:, 1].view(1, -1)
     overlaps_h = torch.clamp(torch.min(a_bottom, b_bottom) - torch.max(a_top, b_top), min=0)
-
     overlaps_3d = overlaps_bev * overlaps_h
     vol_a = (boxes_a[:, 3] * boxes_a[:, 4] * boxes_a[:, 5]).view(-1, 1)
     vol_b = (boxes_b[:, 3] * boxes_b[:, 4] * boxes_b[:, 5]).view(1, -1)

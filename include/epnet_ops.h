@@ -139,6 +139,17 @@ int epnet_boxes_overlap_bev(int num_a, const float *boxes_a, int num_b, const fl
 int epnet_boxes_iou_bev(int num_a, const float *boxes_a, int num_b, const float *boxes_b,
                         float *ans_iou, epnet_stream_t stream);
 
+/* boxes_iou3d_gpu of lib/utils/iou3d/iou3d_utils.py:21-53 in one launch: boxes (.,7) [x,y,z,h,w,l,ry] ->
+ * ans (num_a,num_b) 3-D IoU = BEV overlap x height overlap / union volume (clamped at 1e-7). The reference
+ * composes boxes3d_to_bev_torch + boxes_overlap_bev_gpu + ~10 elementwise torch kernels; same fp32 operations
+ * in the same order here. */
+int epnet_boxes_iou3d(int num_a, const float *boxes_a, int num_b, const float *boxes_b, float *ans_iou3d,
+                      epnet_stream_t stream);
+
+/* the same for k (a_i, b_i) PAIRS -> ans (k): one launch for what lib/rpn/proposal_target_layer.py:220-247
+ * does with up to 640 single-pair calls per scene */
+int epnet_boxes_iou3d_pairs(int k, const float *boxes_a, const float *boxes_b, float *ans_iou3d, epnet_stream_t stream);
+
 /* bytes of device scratch epnet_nms / epnet_nms_normal need for `boxes_num` boxes */
 size_t epnet_nms_workspace_bytes(int boxes_num);
 

@@ -348,6 +348,21 @@ def test_iou3d_surface_fixture():
         np.testing.assert_array_equal(host(kept), fx[key])
 
 
+def test_fused_iou3d_equals_composition_and_pairs():
+    from epnet_amd import iou3d_utils, synth
+    a = synth.proposal_boxes(512, seed=3, num_objects=20)[0].to(DEV)
+    b = synth.proposal_boxes(20, seed=4, num_objects=20)[0].to(DEV)
+    fused, composed = iou3d_utils.boxes_iou3d_gpu(a, b), iou3d_utils.boxes_iou3d_composed(a, b)
+    np.testing.assert_allclose(host(fused), host(composed), rtol=0, atol=1e-6)
+    assert (host(fused) > 0.05).sum() > 20
+    k = 300
+    pa = a[torch.arange(k) % 512].contiguous()
+    pb = b[torch.arange(k) % 20].contiguous()
+    pairs = iou3d_utils.boxes_iou3d_pairs_gpu(pa, pb)
+    np.testing.assert_array_equal(host(pairs), host(fused)[np.arange(k) % 512, np.arange(k) % 20])
+    assert iou3d_utils.boxes_iou3d_gpu(a[:0], b).shape == (0, 20)
+
+
 @pytest.mark.parametrize("n,thr", [(6300, 0.85), (2700, 0.85), (1000, 0.3), (64, 0.5), (65, 0.5), (1, 0.5)])
 def test_nms_normal_full_size_exact(oracle, n, thr):
     """the training-path NMS (RPN.NMS_TYPE normal): N up to 6300, no trig -> bit-exact keep list"""
