@@ -43,7 +43,7 @@ __global__ __launch_bounds__(kGThreads) void gather_rows_vec4_kernel(int c, int 
         v.y = src[id.y];
         v.z = src[id.z];
         v.w = src[id.w];
-        *reinterpret_cast<float4 *>(dst) = v;
+        store_stream(dst, v.x, v.y, v.z, v.w);
         src += n;
         dst += p;
     }
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kGThreads) void gather_rows_lds_kernel(int c, int n
             v.y = row[id.y];
             v.z = row[id.z];
             v.w = row[id.w];
-            *reinterpret_cast<float4 *>(dst) = v;
+            store_stream(dst, v.x, v.y, v.z, v.w);
             row += n;
             dst += p;
         }

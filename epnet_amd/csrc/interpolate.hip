@@ -306,7 +306,7 @@ __global__ __launch_bounds__(kTiThreads) void three_interpolate_lds_kernel(int c
             float o[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) o[u] = w[u][0] * row[ix[u][0]] + w[u][1] * row[ix[u][1]] + w[u][2] * row[ix[u][2]];
-            *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+            store_stream(dst, o[0], o[1], o[2], o[3]);
             row += m;
             dst += n;
         }
