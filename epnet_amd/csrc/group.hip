@@ -43,7 +43,7 @@ __global__ __launch_bounds__(kGThreads) void gather_rows_vec4_kernel(int c, int 
         v.y = src[id.y];
         v.z = src[id.z];
         v.w = src[id.w];
-        store_stream(dst, v.x, v.y, v.z, v.w);
+        *reinterpret_cast<float4 *>(dst) = v;  // plain store: streaming stores here slowed the kernel that follows
         src += n;
         dst += p;
     }
