@@ -32,11 +32,16 @@ SIGNATURES = {
     "epnet_group_points_grad": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "epnet_group_concat": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "epnet_group_concat_grad": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
+    "epnet_group_points_grad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "epnet_group_points_grad_ws": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "epnet_group_concat_grad_ws": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "epnet_three_nn": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "epnet_three_nn_workspace_bytes": (_sz, [_i, _i, _i]),
     "epnet_three_nn_ws": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "epnet_three_interpolate": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "epnet_three_interpolate_grad": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "epnet_three_interpolate_grad_workspace_bytes": (_sz, [_i, _i, _i]),
+    "epnet_three_interpolate_grad_ws": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "epnet_boxes_overlap_bev": (_i, [_i, _vp, _i, _vp, _vp, _vp]),
     "epnet_boxes_iou_bev": (_i, [_i, _vp, _i, _vp, _vp, _vp]),
     "epnet_boxes_iou3d": (_i, [_i, _vp, _i, _vp, _vp, _vp]),

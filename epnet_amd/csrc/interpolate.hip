@@ -342,6 +342,54 @@ __global__ __launch_bounds__(kTiThreads) void three_interpolate_grad_lds_kernel(
     for (int e = threadIdx.x; e < nr * m; e += kTiThreads) gp[e] += acc[e];
 }
 
+// atomic-free gradient (see scatter_rows_csr_kernel in group.hip): the 3n (unknown, slot) pairs are grouped by
+// their known point; a workgroup stages ROWS rows of grad_out in LDS and every known point j sums
+// w * grad_out over its own list.
+constexpr int kTigThreads = 1024;
+template <int ROWS>
+__global__ __launch_bounds__(kTigThreads) void three_interpolate_grad_csr_kernel(int c, int n, int m,
+                                                                               const float *__restrict__ grad_out,
+                                                                               const float *__restrict__ weight,
+                                                                               const int *__restrict__ offsets,
+                                                                               const int *__restrict__ perm,
+                                                                               float *__restrict__ grad_points) {
+    extern __shared__ float s_go[];  // ROWS * n floats
+    const int bs = blockIdx.y;
+    const int c0 = blockIdx.x * ROWS;
+    const int nr = min(ROWS, c - c0);
+    const float *go = grad_out + ((size_t)bs * c + c0) * n;
+    const int total = nr * n;
+    if ((n & 3) == 0 && ((uintptr_t)go & 15) == 0) {
+        const float4 *src4 = reinterpret_cast<const float4 *>(go);
+        float4 *dst4 = reinterpret_cast<float4 *>(s_go);
+        for (int e = threadIdx.x; e < total / 4; e += kTigThreads) dst4[e] = src4[e];
+    } else {
+        for (int e = threadIdx.x; e < total; e += kTigThreads) s_go[e] = go[e];
+    }
+    __syncthreads();
+    offsets += (size_t)bs * (m + 1);
+    perm += (size_t)bs * n * 3;
+    weight += (size_t)bs * n * 3;
+    float *gp = grad_points + ((size_t)bs * c + c0) * m;
+    for (int j = threadIdx.x; j < m; j += kTigThreads) {
+        const int beg = offsets[j], end = offsets[j + 1];
+        float acc[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
+        for (int t = beg; t < end; ++t) {
+            const int q = perm[t];  // = unknown * 3 + slot
+            const int i = q / 3;
+            const float w = weight[q];
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r)
+                if (r < nr) acc[r] += s_go[r * n + i] * w;
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+            if (r < nr) gp[(size_t)r * m + j] += acc[r];
+    }
+}
+
 __global__ __launch_bounds__(kTiThreads) void three_interpolate_grad_atomic_kernel(int c, int n, int m,
                                                                                    const float *__restrict__ grad_out,
                                                                                    const int *__restrict__ idx,
@@ -454,4 +502,37 @@ extern "C" int epnet_three_nn_ws(int b, int n, int m, const float *unknown, cons
     dim3 grid(div_up(n, kNnIxThreads / 64), b);
     hipLaunchKernelGGL(three_nn_indexed_kernel, grid, dim3(kNnIxThreads), 0, s, n, m, np, unknown, sorted, boxes, dist2, idx);
     return check_launch("three_nn indexed");
+}
+
+extern "C" size_t epnet_three_interpolate_grad_workspace_bytes(int b, int n, int m) {
+    if (b <= 0 || n <= 0 || m <= 0 || m > 16384 || (long long)n * 4 > 128 * 1024) return 0;
+    return (size_t)b * ((size_t)(m + 1) + (size_t)n * 3) * sizeof(int);
+}
+
+extern "C" int epnet_three_interpolate_grad_ws(int b, int c, int n, int m, const float *grad_out, const int *idx,
+                                               const float *weight, float *grad_points, void *workspace,
+                                               size_t workspace_bytes, epnet_stream_t stream) {
+    const size_t need = epnet_three_interpolate_grad_workspace_bytes(b, n, m);
+    if (need == 0) return epnet_three_interpolate_grad(b, c, n, m, grad_out, idx, weight, grad_points, stream);
+    EPNET_REQUIRE(b >= 0 && c >= 0);
+    if (b == 0 || c == 0) return EPNET_OK;
+    EPNET_REQUIRE(grad_out && idx && weight && grad_points && workspace);
+    if (workspace_bytes < need) return EPNET_ENOMEM;
+    if (b > 65535) return EPNET_ELIMIT;
+    hipStream_t s = (hipStream_t)stream;
+    int *offsets = (int *)workspace;
+    int *perm = offsets + (size_t)b * (m + 1);
+    int rc = csr_build_launch(b, m, n * 3, idx, offsets, perm, s);
+    if (rc) return rc;
+    const int fit = (128 * 1024) / (n * 4);
+    const int rows = fit >= 8 ? 8 : fit >= 4 ? 4 : fit >= 2 ? 2 : 1;
+    const size_t lds = (size_t)rows * n * 4;
+    dim3 grid(div_up(c, rows), b);
+    switch (rows) {
+        case 8: hipLaunchKernelGGL(three_interpolate_grad_csr_kernel<8>, grid, dim3(kTigThreads), lds, s, c, n, m, grad_out, weight, offsets, perm, grad_points); break;
+        case 4: hipLaunchKernelGGL(three_interpolate_grad_csr_kernel<4>, grid, dim3(kTigThreads), lds, s, c, n, m, grad_out, weight, offsets, perm, grad_points); break;
+        case 2: hipLaunchKernelGGL(three_interpolate_grad_csr_kernel<2>, grid, dim3(kTigThreads), lds, s, c, n, m, grad_out, weight, offsets, perm, grad_points); break;
+        default: hipLaunchKernelGGL(three_interpolate_grad_csr_kernel<1>, grid, dim3(kTigThreads), lds, s, c, n, m, grad_out, weight, offsets, perm, grad_points); break;
+    }
+    return check_launch("three_interpolate_grad");
 }

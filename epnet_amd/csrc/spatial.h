@@ -193,6 +193,9 @@ __device__ __forceinline__ void cell_sort_lds(const float *__restrict__ xyz, int
     __syncthreads();
 }
 
+// defined in group.hip: per scene, offsets (n+1 ints) and perm (p ints) = the positions 0..p-1 grouped by target idx[.] < n <= 16384
+int csr_build_launch(int b, int n, int p, const int *idx, int *offsets, int *perm, hipStream_t s);
+
 // defined in ball_query.hip
 int spatial_index_launch(int b, int n, int np, const float *xyz, float4 *sorted, float *boxes, hipStream_t s);
 

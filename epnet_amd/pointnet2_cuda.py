@@ -43,8 +43,15 @@ def group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_poi
     pg, pi, pp = dev_ptr(grad_out, "grad_out", _F), dev_ptr(idx, "idx", _I), dev_ptr(grad_points, "grad_points", _F)
     need(grad_out, b * c * npoints * nsample, "grad_out"); need(idx, b * npoints * nsample, "idx")
     need(grad_points, b * c * n, "grad_points")
+    l = _lib.lib()
+    ws_bytes = l.epnet_group_points_grad_workspace_bytes(b, n, npoints, nsample)
     with on_device_of(grad_out) as s:
-        _lib.check(_lib.lib().epnet_group_points_grad(b, c, n, npoints, nsample, pg, pi, pp, s), "group_points_grad")
+        if ws_bytes:
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=grad_out.device)
+            _lib.check(l.epnet_group_points_grad_ws(b, c, n, npoints, nsample, pg, pi, pp, ws.data_ptr(), ws_bytes, s),
+                       "group_points_grad")
+        else:
+            _lib.check(l.epnet_group_points_grad(b, c, n, npoints, nsample, pg, pi, pp, s), "group_points_grad")
     return 1
 
 
@@ -105,8 +112,15 @@ def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_point
     pw, pp = dev_ptr(weight, "weight", _F), dev_ptr(grad_points, "grad_points", _F)
     need(grad_out, b * c * n, "grad_out"); need(idx, b * n * 3, "idx"); need(weight, b * n * 3, "weight")
     need(grad_points, b * c * m, "grad_points")
+    l = _lib.lib()
+    ws_bytes = l.epnet_three_interpolate_grad_workspace_bytes(b, n, m)
     with on_device_of(grad_out) as s:
-        _lib.check(_lib.lib().epnet_three_interpolate_grad(b, c, n, m, pg, pi, pw, pp, s), "three_interpolate_grad")
+        if ws_bytes:
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=grad_out.device)
+            _lib.check(l.epnet_three_interpolate_grad_ws(b, c, n, m, pg, pi, pw, pp, ws.data_ptr(), ws_bytes, s),
+                       "three_interpolate_grad")
+        else:
+            _lib.check(l.epnet_three_interpolate_grad(b, c, n, m, pg, pi, pw, pp, s), "three_interpolate_grad")
 
 
 # ---- beyond the reference's nine entry points: fused QueryAndGroup tail -----------------
@@ -131,7 +145,14 @@ def group_concat_wrapper(b, c, n, npoints, nsample, xyz, new_xyz, features, idx,
 def group_concat_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_features, use_xyz):
     pg, pi, pp = dev_ptr(grad_out, "grad_out", _F), dev_ptr(idx, "idx", _I), dev_ptr(grad_features, "grad_features", _F)
     need(grad_out, b * ((3 if use_xyz else 0) + c) * npoints * nsample, "grad_out"); need(grad_features, b * c * n, "grad_features")
+    l = _lib.lib()
+    ws_bytes = l.epnet_group_points_grad_workspace_bytes(b, n, npoints, nsample)
     with on_device_of(grad_out) as s:
-        _lib.check(_lib.lib().epnet_group_concat_grad(b, c, n, npoints, nsample, pg, pi, pp, int(bool(use_xyz)), s),
-                   "group_concat_grad")
+        if ws_bytes:
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=grad_out.device)
+            _lib.check(l.epnet_group_concat_grad_ws(b, c, n, npoints, nsample, pg, pi, pp, int(bool(use_xyz)),
+                                                    ws.data_ptr(), ws_bytes, s), "group_concat_grad")
+        else:
+            _lib.check(l.epnet_group_concat_grad(b, c, n, npoints, nsample, pg, pi, pp, int(bool(use_xyz)), s),
+                       "group_concat_grad")
     return 1

@@ -105,6 +105,17 @@ int epnet_group_concat(int b, int c, int n, int npoints, int nsample, const floa
 int epnet_group_concat_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out, const int *idx,
                             float *grad_features, int use_xyz, epnet_stream_t stream);
 
+/* Gradients of the two grouping forms with caller-supplied device scratch: the scatter-add is inverted (the
+ * positions are grouped by target point, then every target sums its own list out of LDS) so that no atomic
+ * is needed. Same result up to the summation order, which the reference's atomicAdd leaves unspecified too.
+ * A workspace size of 0 means the scratch-free kernels are used anyway. */
+size_t epnet_group_points_grad_workspace_bytes(int b, int n, int npoints, int nsample);
+int epnet_group_points_grad_ws(int b, int c, int n, int npoints, int nsample, const float *grad_out, const int *idx,
+                               float *grad_points, void *workspace, size_t workspace_bytes, epnet_stream_t stream);
+int epnet_group_concat_grad_ws(int b, int c, int n, int npoints, int nsample, const float *grad_out, const int *idx,
+                               float *grad_features, int use_xyz, void *workspace, size_t workspace_bytes,
+                               epnet_stream_t stream);
+
 /* three_nn_kernel_launcher_fast, interpolate_gpu.cu:55-74.
  * unknown (B,n,3), known (B,m,3) -> dist2 (B,n,3) f32 squared distances, idx (B,n,3) i32 */
 int epnet_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2,
@@ -126,6 +137,12 @@ int epnet_three_interpolate(int b, int c, int m, int n, const float *points, con
  * grad_out (B,C,n), idx, weight (B,n,3) -> grad_points (B,C,m) accumulated into (caller-zeroed) */
 int epnet_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out, const int *idx,
                                  const float *weight, float *grad_points, epnet_stream_t stream);
+
+/* atomic-free form of the above with caller scratch (inverse index over the known points); 0 bytes = not used */
+size_t epnet_three_interpolate_grad_workspace_bytes(int b, int n, int m);
+int epnet_three_interpolate_grad_ws(int b, int c, int n, int m, const float *grad_out, const int *idx,
+                                    const float *weight, float *grad_points, void *workspace, size_t workspace_bytes,
+                                    epnet_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------
  * iou3d (lib/utils/iou3d/src/iou3d.cpp:174-179); boxes are (N,5) [x1,y1,x2,y2,ry] f32
