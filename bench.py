@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-overlap", action="store_true",
                     help="single stream: do not run ball query / grouping of level l beside the FPS of level l+1")
+    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("EPNET_BENCH_IN_FLIGHT", "1")),
+                    help="batches in flight: step k is issued on HIP stream k %% L with its own buffers, so the latency-"
+                         "bound sampling chain of one batch runs beside the bandwidth-bound grouping of the previous one")
     ap.add_argument("--with-fp", action="store_true", help="also run the 4 three_nn + 4 three_interpolate FP ops")
     ap.add_argument("--cpu-scenes", type=int, default=int(os.environ.get("EPNET_BENCH_CPU_SCENES", "16")),
                     help="scenes in the cpu_baseline sample (0 = skip)")
@@ -172,25 +175,36 @@ def main():
             torch.cuda.synchronize()
 
     def time_stack(batch, steps, warmup):
-        """returns (seconds for `steps` steps, the stack, its input)"""
-        ids = scene_shard.scene_ids(batch * world, rank, world)           # round-robin shard of the global batch
+        """returns (seconds for `steps` steps, the first lane's stack, its input)"""
         fn = {"ubox": synth.ubox_cloud, "kitti": synth.kitti_like_cloud, "dup": synth.dup_cloud}[args.kind]
-        xyz = torch.stack([fn(args.points, scene_shard.scene_seed(1, i)) for i in ids]).to(dev)  # inputs resident in HBM
-        stack = sa_stack.SAStack(batch, n=args.points, device=dev, with_fp=args.with_fp, seed=rank,
-                                 overlap=not args.no_overlap)
-        if args.no_graph:
-            step = lambda: stack.run(xyz)
-        else:
-            stack.capture(xyz)
-            step = stack.replay
-        for _ in range(warmup):
-            step()
+        lanes = []
+        for k in range(max(1, args.in_flight)):
+            # round-robin shard of the global batch; every lane (batch in flight) has its own scenes and buffers
+            ids = scene_shard.scene_ids(batch * world, rank, world)
+            xyz = torch.stack([fn(args.points, scene_shard.scene_seed(1 + k, i)) for i in ids]).to(dev)  # resident in HBM
+            stack = sa_stack.SAStack(batch, n=args.points, device=dev, with_fp=args.with_fp, seed=rank + 1000 * k,
+                                     overlap=not args.no_overlap)
+            stream = torch.cuda.Stream(device=dev) if args.in_flight > 1 else torch.cuda.current_stream(dev)
+            if not args.no_graph:
+                stack.capture(xyz)
+            lanes.append((stack, xyz, stream))
+
+        def step(i):
+            stack, xyz, stream = lanes[i % len(lanes)]
+            with torch.cuda.stream(stream):
+                if args.no_graph:
+                    stack.run(xyz)
+                else:
+                    stack.replay()
+
+        for i in range(warmup):
+            step(i)
         barrier()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
+        for i in range(steps):
+            step(i)
         barrier()
-        return time.perf_counter() - t0, stack, xyz
+        return time.perf_counter() - t0, lanes[0][0], lanes[0][1]
 
     elapsed, stack, xyz = time_stack(args.batch, args.steps, args.warmup)
     reduce_dev = dev if dist.is_initialized() and dist.get_backend() == "nccl" else "cpu"
@@ -250,7 +264,7 @@ def main():
                                    "radii [[.1,.5],[.5,1],[1,2],[2,4]], nsample [16,32], C=0/96/256/512, %s launch"
                                    % (args.batch, args.points, args.kind, " + 4 three_nn + 4 three_interpolate" if args.with_fp else "",
                                       "eager" if args.no_graph else "HIP-graph"),
-                       "scenes_per_gpu": args.batch, "points_per_scene": args.points, "parallelism": "scene-parallel x%d" % world},
+                       "scenes_per_gpu": args.batch, "steps_in_flight": max(1, args.in_flight), "points_per_scene": args.points, "parallelism": "scene-parallel x%d" % world},
             "points_per_s_per_gpu": round(value / world, 1),
             "stack_algorithmic_GBps_per_gpu": round(stack_gbs, 2), "stack_hbm_frac": round(stack_gbs / HBM_PEAK_GBS, 6),
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,

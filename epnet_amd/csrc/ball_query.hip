@@ -291,33 +291,8 @@ int epnet::spatial_index_launch(int b, int n, int np, const float *xyz, float4 *
     return check_launch("spatial index");
 }
 
-static int bq_padded(int n) {
-    int np = 2048;
-    while (np < n) np <<= 1;
-    return np;
-}
-
-extern "C" size_t epnet_ball_query_workspace_bytes(int b, int n, int m) {
-    if (b <= 0 || n < 2048 || n > kIxMaxPoints || m <= 0) return 0;  // small or huge scenes: direct scan, no scratch
-    const size_t np = (size_t)bq_padded(n);
-    return (size_t)b * (np * sizeof(float4) + (np / 64) * 6 * sizeof(float));
-}
-
-extern "C" int epnet_ball_query_ws(int b, int n, int m, float radius, int nsample, const float *new_xyz,
-                                   const float *xyz, int *idx, void *workspace, size_t workspace_bytes,
-                                   epnet_stream_t stream) {
-    const size_t need = epnet_ball_query_workspace_bytes(b, n, m);
-    if (need == 0 || nsample <= 0) return epnet_ball_query(b, n, m, radius, nsample, new_xyz, xyz, idx, stream);
-    EPNET_REQUIRE(new_xyz && xyz && idx && workspace);
-    if (workspace_bytes < need) return EPNET_ENOMEM;
-    if (((uintptr_t)workspace & 15) != 0) return EPNET_EINVAL;
-    EPNET_REQUIRE(b <= 65535);
-    hipStream_t s = (hipStream_t)stream;
-    const int np = bq_padded(n);
-    float4 *sorted = (float4 *)workspace;
-    float *boxes = (float *)(sorted + (size_t)b * np);
-    int rc = spatial_index_launch(b, n, np, xyz, sorted, boxes, s);
-    if (rc) return rc;
+static int bq_query_launch(int b, int np, int m, float radius, int nsample, const float *new_xyz, const float4 *sorted,
+                           const float *boxes, int *idx, hipStream_t s) {
     const float radius2 = radius * radius;  // ball_query_gpu.cu:23
     dim3 grid(div_up(m, kQThreads / 64), b);
     switch (np / 2048) {
@@ -329,4 +304,49 @@ extern "C" int epnet_ball_query_ws(int b, int n, int m, float radius, int nsampl
         default: hipLaunchKernelGGL(bq_query_kernel<32>, grid, dim3(kQThreads), 0, s, np, m, radius2, nsample, new_xyz, sorted, boxes, idx); break;
     }
     return check_launch("ball_query query");
+}
+
+extern "C" size_t epnet_scene_index_bytes(int b, int n) { return scene_index_bytes(b, n); }
+
+extern "C" int epnet_scene_index_build(int b, int n, const float *xyz, void *index, size_t index_bytes,
+                                       epnet_stream_t stream) {
+    const size_t need = scene_index_bytes(b, n);
+    EPNET_REQUIRE(need != 0 && xyz && index);
+    if (index_bytes < need) return EPNET_ENOMEM;
+    if (((uintptr_t)index & 15) != 0) return EPNET_EINVAL;
+    EPNET_REQUIRE(b <= 65535);
+    const int np = scene_index_np(n);
+    float4 *sorted = (float4 *)index;
+    return spatial_index_launch(b, n, np, xyz, sorted, (float *)(sorted + (size_t)b * np), (hipStream_t)stream);
+}
+
+extern "C" int epnet_ball_query_indexed(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                                        const float *xyz, const void *index, size_t index_bytes, int *idx,
+                                        epnet_stream_t stream) {
+    const size_t need = scene_index_bytes(b, n);
+    if (need == 0 || !index || nsample <= 0 || m <= 0)
+        return epnet_ball_query(b, n, m, radius, nsample, new_xyz, xyz, idx, stream);
+    EPNET_REQUIRE(new_xyz && idx);
+    if (index_bytes < need) return EPNET_ENOMEM;
+    EPNET_REQUIRE(b <= 65535);
+    const int np = scene_index_np(n);
+    const float4 *sorted = (const float4 *)index;
+    return bq_query_launch(b, np, m, radius, nsample, new_xyz, sorted, (const float *)(sorted + (size_t)b * np), idx,
+                           (hipStream_t)stream);
+}
+
+extern "C" size_t epnet_ball_query_workspace_bytes(int b, int n, int m) {
+    if (n < 2048 || m <= 0) return 0;  // small or huge scenes: direct scan, no scratch
+    return scene_index_bytes(b, n);
+}
+
+extern "C" int epnet_ball_query_ws(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                                   const float *xyz, int *idx, void *workspace, size_t workspace_bytes,
+                                   epnet_stream_t stream) {
+    const size_t need = epnet_ball_query_workspace_bytes(b, n, m);
+    if (need == 0 || nsample <= 0) return epnet_ball_query(b, n, m, radius, nsample, new_xyz, xyz, idx, stream);
+    EPNET_REQUIRE(new_xyz && xyz && idx && workspace);
+    int rc = epnet_scene_index_build(b, n, xyz, workspace, workspace_bytes, stream);
+    if (rc) return rc;
+    return epnet_ball_query_indexed(b, n, m, radius, nsample, new_xyz, xyz, workspace, workspace_bytes, idx, stream);
 }

@@ -263,12 +263,16 @@ namespace pruned {
 #ifdef EPNET_FPS_STATS  // diagnostic build only (scratch/fps_stats.hip): phase cycle counters
 __device__ unsigned long long g_stats[16];
 #define EPNET_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
-#define EPNET_ACC(slot, a, b) if ((threadIdx.x & 63) == 0) atomicAdd(&g_stats[slot], (unsigned long long)((b) - (a)))
-#define EPNET_CNT(slot, v) if ((threadIdx.x & 63) == 0) atomicAdd(&g_stats[slot], (unsigned long long)(v))
+#define EPNET_ACC(slot, a, b) st_acc[slot] += (unsigned long long)((b) - (a))
+#define EPNET_CNT(slot, v) st_acc[slot] += (unsigned long long)(v)
+#define EPNET_STATS_BEGIN unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define EPNET_STATS_END if ((threadIdx.x & 63) == 0) for (int s_ = 0; s_ < 8; ++s_) atomicAdd(&g_stats[s_], st_acc[s_])
 #else
 #define EPNET_STAMP(var)
 #define EPNET_ACC(slot, a, b)
 #define EPNET_CNT(slot, v)
+#define EPNET_STATS_BEGIN
+#define EPNET_STATS_END
 #endif
 
 __device__ __forceinline__ unsigned rank14(int k) { return (bitrev_lg((unsigned)k & 1023u, 10) << 4) | ((unsigned)k >> 10); }
@@ -329,62 +333,28 @@ __device__ __forceinline__ unsigned fold_parts(unsigned long long a) {
     return (unsigned)a & (PPT >= 32 ? 0xFFFFFFFFu : ((1u << PPT) - 1u));
 }
 
-// W waves per scene (4: one per SIMD; 8 for N > 8192), PPT slots of 64 points per wave.
+constexpr int kIdxBufP = 1024;  // selected ranks buffered in LDS between flushes
+
+// The M-1 rounds. W waves per scene (4: one per SIMD; 8 for N > 8192), PPT slots of 64 points per wave;
+// thread (wave, lane) holds in slot j the point at sorted position ((j*kW + wave) << 6) | lane: coordinates,
+// running distance t (bits; -1.0f = padding) and reference rank rk.
 // A slot is split into 64/PPT parts of PPT lanes: these parts are the pruning buckets, and bucket
 // (slot j, part p) is summarised in lane p*PPT + j -- a lane of the part itself, so a part's maximum
 // reaches its summary lane with an in-row DPP reduction and a lane-id compare, no cross-lane move.
-template <int kW, int PPT>
-__global__ __launch_bounds__(64 * kW) void fps_pruned_kernel(int n, int m, const float *__restrict__ xyz,
-                                                             float *__restrict__ temp, int *__restrict__ idxs) {
-    typedef float vecf __attribute__((ext_vector_type(PPT)));
-    typedef int veci __attribute__((ext_vector_type(PPT)));
-    constexpr int kT = 64 * kW;
-    constexpr int NP = kT * PPT;  // padded point count (power of two)
-    extern __shared__ int s_dyn[];  // cell histogram, then NP 16-bit point indices in cell order
-    int *hist = s_dyn;
-    unsigned short *perm = reinterpret_cast<unsigned short *>(s_dyn + kCells + kCells / (kCells / kT) + 64);
-    __shared__ int s_part[16];
-    __shared__ float s_box[6][16];
-    __shared__ int s_val[2][16];
+// Cross-wave arg-max: every wave's best point enters ONE 64-bit LDS atomic max on the key
+// (distance bits << 32 | (0x3FFF - rank) << 4 | wave): the larger distance wins, equal distances go to the
+// smaller reference rank -- and after the round's single barrier the winner is read back with two
+// dependent LDS loads (key, then that wave's coordinates), no cross-lane reduction at all.
+template <int kW, int PPT, typename VF, typename VI>
+__device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, const VF &z, VI &t, const VI &rk,
+                                           float cx, float cy, float cz, int *__restrict__ idxs) {
+    __shared__ unsigned long long s_key[3];
     __shared__ float4 s_rec[2][16];
-    __shared__ int s_idx[kIdxBuf];
+    __shared__ int s_idx[kIdxBufP];
     const int q = threadIdx.x;
     const int lane = q & 63, wave = q >> 6;
     const int sub = lane & (PPT - 1);  // the slot this lane summarises (for its own part)
-    xyz += (size_t)blockIdx.x * n * 3;
-    if (temp) temp += (size_t)blockIdx.x * n;
-    idxs += (size_t)blockIdx.x * m;
     const int kNeg1 = __float_as_int(-1.f);
-
-    // ---- spatial order: counting sort by grid cell (spatial.h); positions >= n are padding
-    float lo[3], ext[3];
-    block_bbox3(xyz, n, s_box, lo, ext);
-    const CellGrid grid = make_cell_grid(lo, ext);
-    cell_sort_lds(xyz, n, grid, hist, s_part, perm);
-
-    // ---- sorted position p = (group << 6 | lane); group g of 64 sorted points -> (wave g % kW, slot g / kW)
-    // perm[] is turned in place into the table of reference ranks (0xFFFF = padding): entry p is only ever
-    // touched by the thread that owns position p
-    vecf x, y, z;
-    veci t;
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-        const int p = ((j * kW + wave) << 6) | lane;
-        unsigned r16 = 0xFFFFu;
-        if (p < n) {
-            const int k = (int)perm[p];
-            r16 = rank14(k);
-            x[j] = xyz[k * 3 + 0];
-            y[j] = xyz[k * 3 + 1];
-            z[j] = xyz[k * 3 + 2];
-            t[j] = __float_as_int(temp ? temp[k] : 1e10f);
-        } else {  // padding: distance pinned at -1
-            x[j] = y[j] = z[j] = 0.f;
-            t[j] = kNeg1;
-        }
-        perm[p] = (unsigned short)r16;
-    }
-    const unsigned short *rank16 = perm;
 
     // ---- bucket summaries
     int bm = kNeg1;
@@ -405,12 +375,18 @@ __global__ __launch_bounds__(64 * kW) void fps_pruned_kernel(int n, int m, const
             loz = any ? mnz : 0.f; hiz = any ? mxz : 0.f;
         }
     }
-    if (q < 32) s_val[q >> 4][q & 15] = kNeg1;
-    if (q == 0) s_idx[0] = 0;
-    float cx = xyz[0], cy = xyz[1], cz = xyz[2];
+    if (q < 3) s_key[q] = 0ull;
+    if (q == 0) s_idx[0] = 0;  // rank 0 == point 0
     __syncthreads();
 
+    EPNET_STATS_BEGIN;
     EPNET_STAMP(t_loop0);
+    // this wave's best point, recomputed only in rounds that changed one of its buckets
+    bool stale = true;
+    int wbest = kNeg1;
+    unsigned racc = 0xFFFFFFFFu;  // != ~0 in the one lane that publishes
+    float xa = 0.f, ya = 0.f, za = 0.f;
+    int kb = 1;  // key slot of the round = it % 3
     for (int it = 1; it < m; ++it) {
         EPNET_STAMP(t0);
         // A. which buckets can change?
@@ -420,6 +396,7 @@ __global__ __launch_bounds__(64 * kW) void fps_pruned_kernel(int n, int m, const
         const float L = bdx * bdx + bdy * bdy + bdz * bdz;
         unsigned active = fold_parts<PPT>(__ballot(__float_as_int(L) < bm));
         EPNET_CNT(0, __popc(active));
+        stale = stale || active != 0u;
         EPNET_STAMP(t1);
         // B. update the slots that contain one
         while (active) {
@@ -434,64 +411,167 @@ __global__ __launch_bounds__(64 * kW) void fps_pruned_kernel(int n, int m, const
         }
         EPNET_STAMP(t2);
         // C. this wave's maximum; the points that hold it (usually exactly one) compete by reference rank
-        const int wbest = wave_max_all(bm);
-        unsigned cand = fold_parts<PPT>(__ballot(bm == wbest));
-        unsigned racc = 0xFFFFFFFFu;
-        float xa = 0.f, ya = 0.f, za = 0.f;
-        int holders = 0;
-        do {
-            const int j = (int)__builtin_ctz(cand);
-            cand &= cand - 1u;
-            const unsigned rk = rank16[((j * kW + wave) << 6) | lane];  // LDS; latency hidden behind the indexed reads
-            const bool eq = t[j] == wbest;
-            holders += (int)__popcll(__ballot(eq));
-            const unsigned r = eq ? rk : 0xFFFFFFFFu;
-            const bool take = r < racc;
-            racc = take ? r : racc;
-            xa = take ? x[j] : xa;
-            ya = take ? y[j] : ya;
-            za = take ? z[j] : za;
-        } while (cand);
-        // one holder (the rule): that lane publishes; several equal maxima: the smallest rank does
-        const unsigned rmin = holders == 1 ? 0xFFFFFFFEu : wave_min_all(racc);
+        if (stale) {
+            stale = false;
+            wbest = wave_max_all(bm);
+            unsigned cand = fold_parts<PPT>(__ballot(bm == wbest));
+            racc = 0xFFFFFFFFu;
+            int holders = 0;
+            do {
+                const int j = (int)__builtin_ctz(cand);
+                cand &= cand - 1u;
+                const bool eq = t[j] == wbest;
+                holders += (int)__popcll(__ballot(eq));
+                const unsigned r = eq ? (unsigned)rk[j] : 0xFFFFFFFFu;
+                const bool take = r < racc;
+                racc = take ? r : racc;
+                xa = take ? x[j] : xa;
+                ya = take ? y[j] : ya;
+                za = take ? z[j] : za;
+            } while (cand);
+            if (holders != 1) {  // several equal maxima in this wave: only the smallest rank stays a publisher
+                const unsigned rmin = wave_min_all(racc);
+                racc = racc == rmin ? racc : 0xFFFFFFFFu;
+            }
+            if (wbest == kNeg1) racc = 0xFFFFFFFFu;  // a wave of padding only
+        }
         const int buf = it & 1;
-        if (holders == 1 ? racc != 0xFFFFFFFFu : racc == rmin) {
-            s_val[buf][wave] = wbest;
-            s_rec[buf][wave] = make_float4(xa, ya, za, __uint_as_float(racc));
+        if (racc != 0xFFFFFFFFu) {
+            s_rec[buf][wave] = make_float4(xa, ya, za, 0.f);
+            const unsigned long long key =
+                ((unsigned long long)(unsigned)wbest << 32) | (unsigned long long)(((0x3FFFu - racc) << 4) | (unsigned)wave);
+            __hip_atomic_fetch_max(&s_key[kb], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         EPNET_STAMP(t3);
         __syncthreads();
         EPNET_STAMP(t4);
-        // D. best wave: the records are replicated with period kW along the lanes
-        const int wv = s_val[buf][lane & (kW - 1)];
-        const float4 rec = s_rec[buf][lane & (kW - 1)];
-        const int bmx = period_max<kW>(wv);
-        const unsigned r2 = (wv == bmx) ? __float_as_uint(rec.w) : 0xFFFFFFFFu;
-        const unsigned r2min = period_min<kW>(r2);
-        const int wl = (int)__builtin_ctzll(__ballot(r2 == r2min));  // a lane holding the winning record
-        cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rec.x), wl));
-        cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rec.y), wl));
-        cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rec.z), wl));
-        const int wrank = __builtin_amdgcn_readlane((int)r2min, wl);
-        if (wave == 0) s_idx[it & (kIdxBuf - 1)] = wrank;  // all lanes, same word; converted to an index at the flush
-        if ((it & (kIdxBuf - 1)) == kIdxBuf - 1 && wave == 0) {
-            const int base = it - (kIdxBuf - 1);
-            for (int e = lane; e < kIdxBuf; e += 64) idxs[base + e] = (base + e) ? unrank14((unsigned)s_idx[e]) : 0;
+        // D. the winner: key, then its wave's coordinates (both loads are wave-uniform broadcasts)
+        const unsigned klo = (unsigned)s_key[kb];
+        const float4 rec = s_rec[buf][klo & 15u];
+        cx = rec.x;
+        cy = rec.y;
+        cz = rec.z;
+        const int kb2 = kb == 0 ? 2 : kb - 1;  // == (it + 2) % 3: last read in round it-1, next used in round it+2
+        kb = kb == 2 ? 0 : kb + 1;
+        if (wave == 0) {
+            s_idx[it & (kIdxBufP - 1)] = (int)(0x3FFFu - (klo >> 4));  // all lanes, same word; converted at the flush
+            if (lane == 0) s_key[kb2] = 0ull;
+            if ((it & (kIdxBufP - 1)) == kIdxBufP - 1) {
+                const int base = it - (kIdxBufP - 1);
+                for (int e = lane; e < kIdxBufP; e += 64) idxs[base + e] = unrank14((unsigned)s_idx[e]);
+            }
         }
         EPNET_STAMP(t5);
         EPNET_ACC(1, t0, t1); EPNET_ACC(2, t1, t2); EPNET_ACC(3, t2, t3); EPNET_ACC(4, t3, t4); EPNET_ACC(5, t4, t5);
     }
     EPNET_STAMP(t_loop1);
     EPNET_ACC(6, t_loop0, t_loop1);
+    EPNET_STATS_END;
     if (wave == 0) {
-        const int base = (m - 1) & ~(kIdxBuf - 1);
-        for (int e = lane; base + e < m; e += 64) idxs[base + e] = (base + e) ? unrank14((unsigned)s_idx[e]) : 0;
+        const int base = (m - 1) & ~(kIdxBufP - 1);
+        for (int e = lane; base + e < m; e += 64) idxs[base + e] = unrank14((unsigned)s_idx[e]);
     }
-    if (temp) {
-        for (int j = 0; j < PPT; ++j) {
-            const unsigned rk = rank16[((j * kW + wave) << 6) | lane];
-            if (rk != 0xFFFFu) temp[unrank14(rk)] = __int_as_float(t[j]);
+}
+
+// Self-contained kernel (no caller scratch): counting-sorts the scene by grid cell in LDS, then runs the rounds.
+template <int kW, int PPT>
+__global__ __launch_bounds__(64 * kW) void fps_pruned_kernel(int n, int m, const float *__restrict__ xyz,
+                                                             float *__restrict__ temp, int *__restrict__ idxs) {
+    typedef float vecf __attribute__((ext_vector_type(PPT)));
+    typedef int veci __attribute__((ext_vector_type(PPT)));
+    constexpr int kT = 64 * kW;
+    extern __shared__ int s_dyn[];  // cell histogram, then the 16-bit point indices in cell order
+    int *hist = s_dyn;
+    unsigned short *perm = reinterpret_cast<unsigned short *>(s_dyn + kCells + kCells / (kCells / kT) + 64);
+    __shared__ int s_part[16];
+    __shared__ float s_box[6][16];
+    const int q = threadIdx.x;
+    const int lane = q & 63, wave = q >> 6;
+    xyz += (size_t)blockIdx.x * n * 3;
+    if (temp) temp += (size_t)blockIdx.x * n;
+    idxs += (size_t)blockIdx.x * m;
+
+    // ---- spatial order: counting sort by grid cell (spatial.h); positions >= n are padding
+    float lo[3], ext[3];
+    block_bbox3(xyz, n, s_box, lo, ext);
+    const CellGrid grid = make_cell_grid(lo, ext);
+    cell_sort_lds(xyz, n, grid, hist, s_part, perm);
+
+    // ---- sorted position p = (group << 6 | lane); group g of 64 sorted points -> (wave g % kW, slot g / kW)
+    veci kk;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int p = ((j * kW + wave) << 6) | lane;
+        kk[j] = p < n ? (int)perm[p] : -1;
+    }
+    vecf x, y, z;
+    veci t, rk;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int k = kk[j];
+        if (k >= 0) {
+            x[j] = xyz[k * 3 + 0];
+            y[j] = xyz[k * 3 + 1];
+            z[j] = xyz[k * 3 + 2];
+            t[j] = __float_as_int(temp ? temp[k] : 1e10f);
+            rk[j] = (int)rank14(k);
+        } else {  // padding: distance pinned at -1
+            x[j] = y[j] = z[j] = 0.f;
+            t[j] = __float_as_int(-1.f);
+            rk[j] = 0xFFFF;
         }
+    }
+    fps_rounds<kW, PPT>(m, x, y, z, t, rk, xyz[0], xyz[1], xyz[2], idxs);
+    if (temp) {
+#pragma unroll
+        for (int j = 0; j < PPT; ++j)
+            if (rk[j] != 0xFFFF) temp[unrank14((unsigned)rk[j])] = __int_as_float(t[j]);
+    }
+}
+
+// Same rounds over a scene index built beforehand (spatial.h: cell-sorted float4 copy x, y, z, original index;
+// padding entries carry index -1). Needs no dynamic LDS, so it shares a CU with the bandwidth-bound kernels.
+template <int kW, int PPT>
+__global__ __launch_bounds__(64 * kW) void fps_indexed_kernel(int n, int m, const float4 *__restrict__ sorted,
+                                                              float *__restrict__ temp, int *__restrict__ idxs) {
+    typedef float vecf __attribute__((ext_vector_type(PPT)));
+    typedef int veci __attribute__((ext_vector_type(PPT)));
+    constexpr int NP = 64 * kW * PPT;
+    __shared__ float s_first[4];
+    const int q = threadIdx.x;
+    const int lane = q & 63, wave = q >> 6;
+    sorted += (size_t)blockIdx.x * NP;
+    if (temp) temp += (size_t)blockIdx.x * n;
+    idxs += (size_t)blockIdx.x * m;
+    vecf x, y, z;
+    veci t, rk;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const float4 v = sorted[((j * kW + wave) << 6) | lane];
+        const int k = __float_as_int(v.w);
+        if (k >= 0) {
+            x[j] = v.x;
+            y[j] = v.y;
+            z[j] = v.z;
+            t[j] = __float_as_int(temp ? temp[k] : 1e10f);
+            rk[j] = (int)rank14(k);
+            if (k == 0) {  // the first sample is point 0 (sampling_gpu.cu:118)
+                s_first[0] = v.x;
+                s_first[1] = v.y;
+                s_first[2] = v.z;
+            }
+        } else {
+            x[j] = y[j] = z[j] = 0.f;
+            t[j] = __float_as_int(-1.f);
+            rk[j] = 0xFFFF;
+        }
+    }
+    __syncthreads();
+    fps_rounds<kW, PPT>(m, x, y, z, t, rk, s_first[0], s_first[1], s_first[2], idxs);
+    if (temp) {
+#pragma unroll
+        for (int j = 0; j < PPT; ++j)
+            if (rk[j] != 0xFFFF) temp[unrank14((unsigned)rk[j])] = __int_as_float(t[j]);
     }
 }
 
@@ -659,5 +739,32 @@ extern "C" int epnet_furthest_point_sampling(int b, int n, int m, const float *x
     if (!tbuf) return EPNET_EINVAL;  // temp may only be NULL on the register-resident path
     const int bs = bs_ref < 64 ? 64 : bs_ref;
     hipLaunchKernelGGL(fps_stream_kernel, grid, dim3(bs), 0, s, n, m, lg, xyz, tbuf, idx);
+    return check_launch("furthest_point_sampling");
+}
+
+extern "C" int epnet_furthest_point_sampling_indexed(int b, int n, int m, const float *xyz, const void *index,
+                                                     size_t index_bytes, float *temp, int *idx,
+                                                     epnet_stream_t stream) {
+    const size_t need = scene_index_bytes(b, n);
+    if (need == 0 || !index || n > 16384 || m <= 1)
+        return epnet_furthest_point_sampling(b, n, m, xyz, temp, idx, stream);
+    EPNET_REQUIRE(idx);
+    if (index_bytes < need) return EPNET_ENOMEM;
+    hipStream_t s = (hipStream_t)stream;
+    const float4 *sorted = (const float4 *)index;
+    dim3 grid(b);
+    static const int wide = getenv("EPNET_FPS_WIDE") ? atoi(getenv("EPNET_FPS_WIDE")) : 0;
+#define EPNET_FPS_INDEXED(W_, P_) \
+    hipLaunchKernelGGL((pruned::fps_indexed_kernel<W_, P_>), grid, dim3(64 * W_), 0, s, n, m, sorted, temp, idx)
+    switch (scene_index_np(n)) {
+        case 2048: EPNET_FPS_INDEXED(4, 8); break;
+        case 4096: EPNET_FPS_INDEXED(4, 16); break;
+        case 8192: EPNET_FPS_INDEXED(4, 32); break;
+        default:
+            if (wide) EPNET_FPS_INDEXED(16, 16);
+            else EPNET_FPS_INDEXED(8, 32);
+            break;
+    }
+#undef EPNET_FPS_INDEXED
     return check_launch("furthest_point_sampling");
 }

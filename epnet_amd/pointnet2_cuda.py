@@ -125,6 +125,59 @@ def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_point
 
 # ---- beyond the reference's nine entry points: fused QueryAndGroup tail -----------------
 
+
+def scene_index(xyz):
+    """one spatial sort of (B,N,3) points, shared by the sampling and the ball queries of an SA level; None where
+    the library indexes nothing (N <= 1024 or N > 65536). include/epnet_ops.h: epnet_scene_index_build"""
+    b, n = xyz.shape[0], xyz.shape[1]
+    l = _lib.lib()
+    nbytes = l.epnet_scene_index_bytes(b, n)
+    if not nbytes:
+        return None
+    px = dev_ptr(xyz, "xyz", _F)
+    need(xyz, b * n * 3, "xyz")
+    index = torch.empty((nbytes,), dtype=torch.uint8, device=xyz.device)
+    with on_device_of(xyz) as s:
+        _lib.check(l.epnet_scene_index_build(b, n, px, index.data_ptr(), nbytes, s), "scene_index_build")
+    return index
+
+
+def scene_index_build_wrapper(b, n, xyz, index):
+    """rebuild into a caller-owned buffer of epnet_scene_index_bytes(b, n) bytes (graph-capturable)"""
+    px = dev_ptr(xyz, "xyz", _F)
+    need(xyz, b * n * 3, "xyz")
+    with on_device_of(xyz) as s:
+        _lib.check(_lib.lib().epnet_scene_index_build(b, n, px, index.data_ptr(), index.numel(), s), "scene_index_build")
+    return 1
+
+
+def _index_args(index, like):
+    if index is None:
+        return None, 0
+    if index.dtype != torch.uint8 or not index.is_contiguous() or index.device != like.device:
+        raise RuntimeError("scene index must be the contiguous uint8 tensor scene_index() returned, on the points' device")
+    return index.data_ptr(), index.numel()
+
+
+def furthest_point_sampling_indexed_wrapper(b, n, m, points, index, temp, idx):
+    """furthest_point_sampling_wrapper over a scene index of `points` (same results)"""
+    pp, pt, pi = dev_ptr(points, "points", _F), dev_ptr(temp, "temp", _F), dev_ptr(idx, "idx", _I)
+    need(points, b * n * 3, "points"); need(temp, b * n, "temp"); need(idx, b * m, "idx")
+    px, nb = _index_args(index, points)
+    with on_device_of(points) as s:
+        _lib.check(_lib.lib().epnet_furthest_point_sampling_indexed(b, n, m, pp, px, nb, pt, pi, s), "furthest_point_sampling")
+    return 1
+
+
+def ball_query_indexed_wrapper(b, n, m, radius, nsample, new_xyz, xyz, index, idx):
+    """ball_query_wrapper over a scene index of `xyz` (same results)"""
+    pn, pxyz, pi = dev_ptr(new_xyz, "new_xyz", _F), dev_ptr(xyz, "xyz", _F), dev_ptr(idx, "idx", _I)
+    need(new_xyz, b * m * 3, "new_xyz"); need(xyz, b * n * 3, "xyz"); need(idx, b * m * nsample, "idx")
+    px, nb = _index_args(index, xyz)
+    with on_device_of(xyz) as s:
+        _lib.check(_lib.lib().epnet_ball_query_indexed(b, n, m, radius, nsample, pn, pxyz, px, nb, pi, s), "ball_query")
+    return 1
+
 def group_concat_wrapper(b, c, n, npoints, nsample, xyz, new_xyz, features, idx, out, use_xyz):
     """out (B, 3+C | C, M, ns) = [grouped xyz - centre ; grouped features]; features may be None when c == 0"""
     px = dev_ptr(xyz, "xyz", _F) if use_xyz else None

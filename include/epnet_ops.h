@@ -145,6 +145,22 @@ int epnet_three_interpolate_grad_ws(int b, int c, int n, int m, const float *gra
                                     epnet_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------
+ * scene index: one spatial sort of a level's points (1024 < n <= 65536), built once in caller scratch and
+ * shared by the sampling and both ball queries of that level (the reference has no counterpart: every one of
+ * its kernels scans all n points). Results are identical to the plain entry points.
+ * epnet_scene_index_bytes returns 0 where no index applies; the *_indexed entry points then (or with
+ * index == NULL) run the plain path.
+ * -------------------------------------------------------------------------------------- */
+size_t epnet_scene_index_bytes(int b, int n);
+int epnet_scene_index_build(int b, int n, const float *xyz, void *index, size_t index_bytes, epnet_stream_t stream);
+/* same contract as epnet_furthest_point_sampling (sampling_gpu.cu:211-253) */
+int epnet_furthest_point_sampling_indexed(int b, int n, int m, const float *xyz, const void *index,
+                                          size_t index_bytes, float *temp, int *idx, epnet_stream_t stream);
+/* same contract as epnet_ball_query (ball_query_gpu.cu:48-66) */
+int epnet_ball_query_indexed(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
+                             const void *index, size_t index_bytes, int *idx, epnet_stream_t stream);
+
+/* ----------------------------------------------------------------------------------------
  * iou3d (lib/utils/iou3d/src/iou3d.cpp:174-179); boxes are (N,5) [x1,y1,x2,y2,ry] f32
  * -------------------------------------------------------------------------------------- */
 

@@ -110,6 +110,62 @@ def test_fps_full_size_properties():
         assert d[idx[3, j]] >= d.max() * (1 - 1e-6)
 
 
+@pytest.mark.parametrize("b,n,m,kind", [
+    (2, 16384, 4096, "kitti"), (2, 16384, 300, "dup"), (2, 8192, 700, "kitti"), (3, 4096, 1024, "kitti"),
+    (2, 2048, 512, "ubox"), (2, 1025, 64, "kitti"), (2, 1500, 1499, "dup"), (2, 10000, 33, "ubox"),
+    (2, 900, 100, "kitti"),      # below the indexed range: index is None, plain path
+    (1, 20000, 20, "kitti"),     # index exists (ball query uses it) but sampling falls back above 16384
+])
+def test_fps_over_scene_index_matches_oracle(oracle, b, n, m, kind):
+    """epnet_furthest_point_sampling_indexed: same indices AND running distances as the plain entry point"""
+    from epnet_amd import pointnet2_cuda as ext
+    xyz = rand_cloud(b, n, seed=300 + n, kind=kind)
+    d_xyz = dev(xyz)
+    index = ext.scene_index(d_xyz)
+    assert (index is None) == (n <= 1024)
+    temp = torch.full((b, n), 1e10, device=DEV)
+    idx = torch.empty((b, m), dtype=torch.int32, device=DEV)
+    ext.furthest_point_sampling_indexed_wrapper(b, n, m, d_xyz, index, temp, idx)
+    o_idx, o_temp = oracle.furthest_point_sampling(xyz, m, return_temp=True)
+    np.testing.assert_array_equal(host(idx), o_idx)
+    np.testing.assert_array_equal(host(temp), o_temp)
+
+
+def test_fps_over_scene_index_ties(oracle):
+    from epnet_amd import pointnet2_cuda as ext
+    rng = np.random.default_rng(5)
+    base = rng.standard_normal((16, 3)).astype(np.float32)
+    lattice = np.stack(np.meshgrid(np.arange(16), np.arange(16), np.arange(8), indexing="ij"), -1).reshape(1, -1, 3)
+    for xyz, m in ((np.ones((2, 2048, 3), np.float32), 7), (base[rng.integers(0, 16, size=(2, 4096))], 100),
+                   (lattice.astype(np.float32), 512)):
+        b, n = xyz.shape[:2]
+        d_xyz = dev(xyz)
+        temp = torch.full((b, n), 1e10, device=DEV)
+        idx = torch.empty((b, m), dtype=torch.int32, device=DEV)
+        ext.furthest_point_sampling_indexed_wrapper(b, n, m, d_xyz, ext.scene_index(d_xyz), temp, idx)
+        np.testing.assert_array_equal(host(idx), oracle.furthest_point_sampling(xyz, m))
+
+
+def test_one_scene_index_serves_sampling_and_both_ball_queries(oracle):
+    """the SA-level call pattern: index once, then FPS + the two MSG ball queries"""
+    from epnet_amd import pointnet2_cuda as ext
+    b, n, m = 2, 16384, 4096
+    xyz = rand_cloud(b, n, seed=77, kind="kitti")
+    d_xyz = dev(xyz)
+    index = torch.empty((ext._lib.lib().epnet_scene_index_bytes(b, n),), dtype=torch.uint8, device=DEV)
+    ext.scene_index_build_wrapper(b, n, d_xyz, index)
+    temp = torch.full((b, n), 1e10, device=DEV)
+    fidx = torch.empty((b, m), dtype=torch.int32, device=DEV)
+    ext.furthest_point_sampling_indexed_wrapper(b, n, m, d_xyz, index, temp, fidx)
+    o_idx = oracle.furthest_point_sampling(xyz, m)
+    np.testing.assert_array_equal(host(fidx), o_idx)
+    new_xyz = np.ascontiguousarray(np.take_along_axis(xyz, o_idx[..., None].astype(np.int64), axis=1))
+    for radius, ns in ((0.1, 16), (0.5, 32)):
+        idx = torch.full((b, m, ns), -7, dtype=torch.int32, device=DEV)
+        ext.ball_query_indexed_wrapper(b, n, m, radius, ns, dev(new_xyz), d_xyz, index, idx)
+        np.testing.assert_array_equal(host(idx), oracle.ball_query(radius, ns, xyz, new_xyz))
+
+
 # ------------------------------------------------------------------------------------------------ ball query
 
 @pytest.mark.parametrize("b,n,m,radius,ns,kind", [
