@@ -43,9 +43,11 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-overlap", action="store_true",
                     help="single stream: do not run ball query / grouping of level l beside the FPS of level l+1")
-    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("EPNET_BENCH_IN_FLIGHT", "1")),
-                    help="batches in flight: step k is issued on HIP stream k %% L with its own buffers, so the latency-"
-                         "bound sampling chain of one batch runs beside the bandwidth-bound grouping of the previous one")
+    ap.add_argument("--pipelined", type=int, default=int(os.environ.get("EPNET_BENCH_PIPELINED", "1")),
+                    help="1: software-pipelined steps -- the (latency-bound) sampling chain of step k runs beside the "
+                         "(bandwidth-bound) ball query + grouping of step k-1, double-buffered; 0: every step alone")
+    ap.add_argument("--unfused", action="store_true", help="grouping as two group_points calls instead of group_concat")
+    ap.add_argument("--no-shared-index", action="store_true", help="every op sorts the scene for itself")
     ap.add_argument("--with-fp", action="store_true", help="also run the 4 three_nn + 4 three_interpolate FP ops")
     ap.add_argument("--cpu-scenes", type=int, default=int(os.environ.get("EPNET_BENCH_CPU_SCENES", "16")),
                     help="scenes in the cpu_baseline sample (0 = skip)")
@@ -116,6 +118,12 @@ class OpTimer:
 
 def op_family(name, head):
     """(family label, algorithmic bytes of this launch) -- formulas of SURVEY.md section 8(d)"""
+    if name.startswith("scene_index"):
+        b, n = head[:2]
+        np_ = 2048
+        while np_ < n:
+            np_ *= 2
+        return "scene_index N=%d" % n, b * (n * 12 + np_ * 16 + np_ // 64 * 24)
     if name.startswith("furthest"):
         b, n, m = head[:3]
         return "fps N=%d M=%d" % (n, m), b * (n * 12 + m * 4)
@@ -128,6 +136,9 @@ def op_family(name, head):
     if name.startswith("group_points_w"):
         b, c, n, m, ns = head[:5]
         return ("group_xyz" if c == 3 else "group_feat"), b * (m * ns * 4 + c * n * 4 + c * m * ns * 4)
+    if name.startswith("group_concat_w"):  # the two grouping calls + centre subtraction + concat of the reference, one output
+        b, c, n, m, ns = head[:5]
+        return "group", b * (m * ns * 4 + 3 * n * 4 + 3 * m * ns * 4) + (b * (m * ns * 4 + c * n * 4 + c * m * ns * 4) if c else 0)
     if name.startswith("three_nn"):
         b, n, m = head[:3]
         return "three_nn", b * (n * 12 + m * 12 + n * 24)
@@ -175,36 +186,26 @@ def main():
             torch.cuda.synchronize()
 
     def time_stack(batch, steps, warmup):
-        """returns (seconds for `steps` steps, the first lane's stack, its input)"""
+        """returns (seconds for `steps` steps, the stack, its input)"""
+        ids = scene_shard.scene_ids(batch * world, rank, world)           # round-robin shard of the global batch
         fn = {"ubox": synth.ubox_cloud, "kitti": synth.kitti_like_cloud, "dup": synth.dup_cloud}[args.kind]
-        lanes = []
-        for k in range(max(1, args.in_flight)):
-            # round-robin shard of the global batch; every lane (batch in flight) has its own scenes and buffers
-            ids = scene_shard.scene_ids(batch * world, rank, world)
-            xyz = torch.stack([fn(args.points, scene_shard.scene_seed(1 + k, i)) for i in ids]).to(dev)  # resident in HBM
-            stack = sa_stack.SAStack(batch, n=args.points, device=dev, with_fp=args.with_fp, seed=rank + 1000 * k,
-                                     overlap=not args.no_overlap)
-            stream = torch.cuda.Stream(device=dev) if args.in_flight > 1 else torch.cuda.current_stream(dev)
-            if not args.no_graph:
-                stack.capture(xyz)
-            lanes.append((stack, xyz, stream))
-
-        def step(i):
-            stack, xyz, stream = lanes[i % len(lanes)]
-            with torch.cuda.stream(stream):
-                if args.no_graph:
-                    stack.run(xyz)
-                else:
-                    stack.replay()
-
-        for i in range(warmup):
-            step(i)
+        xyz = torch.stack([fn(args.points, scene_shard.scene_seed(1, i)) for i in ids]).to(dev)  # inputs resident in HBM
+        stack = sa_stack.SAStack(batch, n=args.points, device=dev, with_fp=args.with_fp, seed=rank,
+                                 overlap=not args.no_overlap, fused=not args.unfused,
+                                 shared_index=not args.no_shared_index, pipelined=bool(args.pipelined))
+        if args.no_graph:
+            step = lambda: stack.step(xyz)
+        else:
+            stack.capture(xyz)
+            step = stack.replay
+        for _ in range(warmup):
+            step()
         barrier()
         t0 = time.perf_counter()
-        for i in range(steps):
-            step(i)
+        for _ in range(steps):
+            step()
         barrier()
-        return time.perf_counter() - t0, lanes[0][0], lanes[0][1]
+        return time.perf_counter() - t0, stack, xyz
 
     elapsed, stack, xyz = time_stack(args.batch, args.steps, args.warmup)
     reduce_dev = dev if dist.is_initialized() and dist.get_backend() == "nccl" else "cpu"
@@ -213,7 +214,7 @@ def main():
     value = points_per_step * args.steps / elapsed
 
     # ---- per-kernel durations: the same K steps replayed eagerly with HIP events around every launch
-    stack.overlap = False  # single stream here, so that an event pair brackets exactly its own kernel
+    stack.overlap = False  # single stream, unpipelined here, so that an event pair brackets exactly its own kernel
     with OpTimer(torch, ext) as timer:
         for _ in range(args.steps):
             stack.run(xyz)
@@ -264,7 +265,7 @@ def main():
                                    "radii [[.1,.5],[.5,1],[1,2],[2,4]], nsample [16,32], C=0/96/256/512, %s launch"
                                    % (args.batch, args.points, args.kind, " + 4 three_nn + 4 three_interpolate" if args.with_fp else "",
                                       "eager" if args.no_graph else "HIP-graph"),
-                       "scenes_per_gpu": args.batch, "steps_in_flight": max(1, args.in_flight), "points_per_scene": args.points, "parallelism": "scene-parallel x%d" % world},
+                       "scenes_per_gpu": args.batch, "software_pipelined": bool(args.pipelined), "points_per_scene": args.points, "parallelism": "scene-parallel x%d" % world},
             "points_per_s_per_gpu": round(value / world, 1),
             "stack_algorithmic_GBps_per_gpu": round(stack_gbs, 2), "stack_hbm_frac": round(stack_gbs / HBM_PEAK_GBS, 6),
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,

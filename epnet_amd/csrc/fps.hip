@@ -335,6 +335,16 @@ __device__ __forceinline__ unsigned fold_parts(unsigned long long a) {
 
 constexpr int kIdxBufP = 1024;  // selected ranks buffered in LDS between flushes
 
+// reference ranks of a thread's PPT points, two 16-bit ranks per register (0xFFFF = padding)
+template <typename VH>
+__device__ __forceinline__ unsigned rank_of(const VH &rk2, int j) {
+    return ((unsigned)rk2[j >> 1] >> ((j & 1) << 4)) & 0xFFFFu;
+}
+template <typename VH>
+__device__ __forceinline__ void set_rank(VH &rk2, int j, unsigned r) {  // j is a compile-time constant at the call sites
+    rk2[j >> 1] = (j & 1) ? (int)(((unsigned)rk2[j >> 1] & 0xFFFFu) | (r << 16)) : (int)r;
+}
+
 // The M-1 rounds. W waves per scene (4: one per SIMD; 8 for N > 8192), PPT slots of 64 points per wave;
 // thread (wave, lane) holds in slot j the point at sorted position ((j*kW + wave) << 6) | lane: coordinates,
 // running distance t (bits; -1.0f = padding) and reference rank rk.
@@ -345,8 +355,8 @@ constexpr int kIdxBufP = 1024;  // selected ranks buffered in LDS between flushe
 // (distance bits << 32 | (0x3FFF - rank) << 4 | wave): the larger distance wins, equal distances go to the
 // smaller reference rank -- and after the round's single barrier the winner is read back with two
 // dependent LDS loads (key, then that wave's coordinates), no cross-lane reduction at all.
-template <int kW, int PPT, typename VF, typename VI>
-__device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, const VF &z, VI &t, const VI &rk,
+template <int kW, int PPT, typename VF, typename VI, typename VH>
+__device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, const VF &z, VI &t, const VH &rk2,
                                            float cx, float cy, float cz, int *__restrict__ idxs) {
     __shared__ unsigned long long s_key[3];
     __shared__ float4 s_rec[2][16];
@@ -422,7 +432,7 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
                 cand &= cand - 1u;
                 const bool eq = t[j] == wbest;
                 holders += (int)__popcll(__ballot(eq));
-                const unsigned r = eq ? (unsigned)rk[j] : 0xFFFFFFFFu;
+                const unsigned r = eq ? rank_of(rk2, j) : 0xFFFFFFFFu;
                 const bool take = r < racc;
                 racc = take ? r : racc;
                 xa = take ? x[j] : xa;
@@ -504,8 +514,10 @@ __global__ __launch_bounds__(64 * kW) void fps_pruned_kernel(int n, int m, const
         const int p = ((j * kW + wave) << 6) | lane;
         kk[j] = p < n ? (int)perm[p] : -1;
     }
+    typedef int vech __attribute__((ext_vector_type(PPT / 2)));
     vecf x, y, z;
-    veci t, rk;
+    veci t;
+    vech rk2;
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
         const int k = kk[j];
@@ -514,18 +526,20 @@ __global__ __launch_bounds__(64 * kW) void fps_pruned_kernel(int n, int m, const
             y[j] = xyz[k * 3 + 1];
             z[j] = xyz[k * 3 + 2];
             t[j] = __float_as_int(temp ? temp[k] : 1e10f);
-            rk[j] = (int)rank14(k);
+            set_rank(rk2, j, rank14(k));
         } else {  // padding: distance pinned at -1
             x[j] = y[j] = z[j] = 0.f;
             t[j] = __float_as_int(-1.f);
-            rk[j] = 0xFFFF;
+            set_rank(rk2, j, 0xFFFFu);
         }
     }
-    fps_rounds<kW, PPT>(m, x, y, z, t, rk, xyz[0], xyz[1], xyz[2], idxs);
+    fps_rounds<kW, PPT>(m, x, y, z, t, rk2, xyz[0], xyz[1], xyz[2], idxs);
     if (temp) {
 #pragma unroll
-        for (int j = 0; j < PPT; ++j)
-            if (rk[j] != 0xFFFF) temp[unrank14((unsigned)rk[j])] = __int_as_float(t[j]);
+        for (int j = 0; j < PPT; ++j) {
+            const unsigned r = rank_of(rk2, j);
+            if (r != 0xFFFFu) temp[unrank14(r)] = __int_as_float(t[j]);
+        }
     }
 }
 
@@ -543,8 +557,10 @@ __global__ __launch_bounds__(64 * kW) void fps_indexed_kernel(int n, int m, cons
     sorted += (size_t)blockIdx.x * NP;
     if (temp) temp += (size_t)blockIdx.x * n;
     idxs += (size_t)blockIdx.x * m;
+    typedef int vech __attribute__((ext_vector_type(PPT / 2)));
     vecf x, y, z;
-    veci t, rk;
+    veci t;
+    vech rk2;
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
         const float4 v = sorted[((j * kW + wave) << 6) | lane];
@@ -554,7 +570,7 @@ __global__ __launch_bounds__(64 * kW) void fps_indexed_kernel(int n, int m, cons
             y[j] = v.y;
             z[j] = v.z;
             t[j] = __float_as_int(temp ? temp[k] : 1e10f);
-            rk[j] = (int)rank14(k);
+            set_rank(rk2, j, rank14(k));
             if (k == 0) {  // the first sample is point 0 (sampling_gpu.cu:118)
                 s_first[0] = v.x;
                 s_first[1] = v.y;
@@ -563,15 +579,17 @@ __global__ __launch_bounds__(64 * kW) void fps_indexed_kernel(int n, int m, cons
         } else {
             x[j] = y[j] = z[j] = 0.f;
             t[j] = __float_as_int(-1.f);
-            rk[j] = 0xFFFF;
+            set_rank(rk2, j, 0xFFFFu);
         }
     }
     __syncthreads();
-    fps_rounds<kW, PPT>(m, x, y, z, t, rk, s_first[0], s_first[1], s_first[2], idxs);
+    fps_rounds<kW, PPT>(m, x, y, z, t, rk2, s_first[0], s_first[1], s_first[2], idxs);
     if (temp) {
 #pragma unroll
-        for (int j = 0; j < PPT; ++j)
-            if (rk[j] != 0xFFFF) temp[unrank14((unsigned)rk[j])] = __int_as_float(t[j]);
+        for (int j = 0; j < PPT; ++j) {
+            const unsigned r = rank_of(rk2, j);
+            if (r != 0xFFFFu) temp[unrank14(r)] = __int_as_float(t[j]);
+        }
     }
 }
 

@@ -126,6 +126,11 @@ def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_point
 # ---- beyond the reference's nine entry points: fused QueryAndGroup tail -----------------
 
 
+def scene_index_bytes(b, n):
+    """bytes of the scene index of b scenes of n points; 0 where the library indexes nothing"""
+    return int(_lib.lib().epnet_scene_index_bytes(b, n))
+
+
 def scene_index(xyz):
     """one spatial sort of (B,N,3) points, shared by the sampling and the ball queries of an SA level; None where
     the library indexes nothing (N <= 1024 or N > 65536). include/epnet_ops.h: epnet_scene_index_build"""

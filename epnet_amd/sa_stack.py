@@ -11,6 +11,13 @@ input of the right shape (C = 0 / 96 / 256 / 512).
 
 Every buffer is allocated once; ``run()`` only launches kernels (through the extension stand-ins,
 i.e. through the C ABI), so the sequence can be captured into a HIP graph (``capture()``).
+
+The stack has two stages with very different machine behaviour:
+  S  the sampling chain (scene index -> FPS -> gather, level after level): a strictly serial, latency-bound
+     chain of one-workgroup-per-scene kernels that needs almost no LDS and no bandwidth;
+  G  ball query + grouping of every level: wide, bandwidth-bound, depends on S only through the centres.
+``pipelined=True`` runs S of batch k beside G of batch k-1 (double-buffered centres / indices), so that in
+steady state a step costs max(S, G) instead of S(level 1) + G.
 """
 import torch
 
@@ -54,13 +61,16 @@ def fp_algorithmic_bytes(fp=RPN_FP):
 
 class SAStack:
     def __init__(self, batch, n=16384, device="cuda", npoints=RPN_NPOINTS, radii=RPN_RADII, nsamples=RPN_NSAMPLES,
-                 feat_channels=RPN_FEAT_CHANNELS, with_fp=False, fp=RPN_FP, seed=0, overlap=True):
+                 feat_channels=RPN_FEAT_CHANNELS, with_fp=False, fp=RPN_FP, seed=0, overlap=True, fused=True,
+                 shared_index=True, pipelined=False):
         self.batch, self.n = batch, n
         # overlap: FPS/gather of level l+1 depend only on the centres of level l (never on features), so
         # the sampling chain runs ahead on the launch stream while ball query + grouping of each level
-        # follow on a second HIP stream (the SA levels' FPS is a latency-bound one-workgroup-per-scene
-        # kernel that leaves the rest of the chip idle)
+        # follow on a second HIP stream
         self.overlap = overlap
+        self.fused = fused                # grouped [xyz - centre ; features] from one kernel (epnet_group_concat)
+        self.shared_index = shared_index  # one scene index per level for FPS + both ball queries
+        self.pipelined = pipelined
         self.side = None
         self.npoints, self.radii, self.nsamples, self.feat_channels = npoints, radii, nsamples, feat_channels
         self.with_fp, self.fp = with_fp, fp
@@ -71,23 +81,28 @@ class SAStack:
         cur = n
         for lvl, m in enumerate(npoints):
             c = feat_channels[lvl]
+            index_bytes = ext.scene_index_bytes(batch, cur) if shared_index else 0
             L = {
                 "n": cur, "m": m, "c": c,
                 "xyz_t": torch.empty((batch, 3, cur), dtype=f32, device=dev),
                 "temp": torch.empty((batch, cur), dtype=f32, device=dev),
                 "fps_idx": torch.empty((batch, m), dtype=i32, device=dev),
                 "new_xyz_t": torch.empty((batch, 3, m), dtype=f32, device=dev),
-                "new_xyz": torch.empty((batch, m, 3), dtype=f32, device=dev),
+                # what G reads from S, one set per pipeline parity
+                "sets": [{"new_xyz": torch.empty((batch, m, 3), dtype=f32, device=dev),
+                          "index": (torch.empty((index_bytes,), dtype=torch.uint8, device=dev) if index_bytes else None)}
+                         for _ in range(2 if pipelined else 1)],
                 "features": (torch.randn((batch, c, cur), generator=g, dtype=f32).to(dev) if c else None),
                 "scales": [],
             }
             for radius, ns in zip(radii[lvl], nsamples[lvl]):
-                L["scales"].append({
-                    "radius": radius, "ns": ns,
-                    "idx": torch.empty((batch, m, ns), dtype=i32, device=dev),
-                    "grouped_xyz": torch.empty((batch, 3, m, ns), dtype=f32, device=dev),
-                    "grouped_feat": (torch.empty((batch, c, m, ns), dtype=f32, device=dev) if c else None),
-                })
+                S = {"radius": radius, "ns": ns, "idx": torch.empty((batch, m, ns), dtype=i32, device=dev)}
+                if fused:
+                    S["grouped"] = torch.empty((batch, 3 + c, m, ns), dtype=f32, device=dev)
+                else:
+                    S["grouped_xyz"] = torch.empty((batch, 3, m, ns), dtype=f32, device=dev)
+                    S["grouped_feat"] = torch.empty((batch, c, m, ns), dtype=f32, device=dev) if c else None
+                L["scales"].append(S)
             self.levels.append(L)
             cur = m
         self.fp_bufs = []
@@ -100,66 +115,146 @@ class SAStack:
                     "idx": torch.empty((batch, nn_, 3), dtype=i32, device=dev),
                     "out": torch.empty((batch, c, nn_), dtype=f32, device=dev),
                 })
-        self.graph = None
+        self.graphs = []
+        self.replays = 0
         self.static_xyz = None
+        if pipelined:  # the centres of both parities, one per "previous batch"
+            self.static_prev = [None, None]
 
-    def _group_level(self, L, cur_xyz):
+    # ---- stage S: the sampling chain of one level
+    def _sample_level(self, L, cur_xyz, parity):
         b, n, m = self.batch, L["n"], L["m"]
-        for S in L["scales"]:
-            ext.ball_query_wrapper(b, n, m, S["radius"], S["ns"], L["new_xyz"], cur_xyz, S["idx"])
+        P = L["sets"][parity]
+        if P["index"] is not None:
+            ext.scene_index_build_wrapper(b, n, cur_xyz, P["index"])
+        L["xyz_t"].copy_(cur_xyz.transpose(1, 2))            # pointnet2_modules.py:30
+        L["temp"].fill_(1e10)                                # pointnet2_utils.py:26
+        if P["index"] is not None:
+            ext.furthest_point_sampling_indexed_wrapper(b, n, m, cur_xyz, P["index"], L["temp"], L["fps_idx"])
+        else:
+            ext.furthest_point_sampling_wrapper(b, n, m, cur_xyz, L["temp"], L["fps_idx"])
+        ext.gather_points_wrapper(b, 3, n, m, L["xyz_t"], L["fps_idx"], L["new_xyz_t"])
+        P["new_xyz"].copy_(L["new_xyz_t"].transpose(1, 2))    # pointnet2_modules.py:42-45
+        return P["new_xyz"]
+
+    # ---- stage G: neighbour search + grouping of one level
+    def _query_scale(self, L, S, cur_xyz, parity):
+        b, n, m = self.batch, L["n"], L["m"]
+        P = L["sets"][parity]
+        if P["index"] is not None:
+            ext.ball_query_indexed_wrapper(b, n, m, S["radius"], S["ns"], P["new_xyz"], cur_xyz, P["index"], S["idx"])
+        else:
+            ext.ball_query_wrapper(b, n, m, S["radius"], S["ns"], P["new_xyz"], cur_xyz, S["idx"])
+
+    def _group_scale(self, L, S, cur_xyz, parity):
+        b, n, m = self.batch, L["n"], L["m"]
+        if self.fused:   # pointnet2_utils.py:249-257 in one call
+            ext.group_concat_wrapper(b, L["c"], n, m, S["ns"], cur_xyz, L["sets"][parity]["new_xyz"], L["features"],
+                                     S["idx"], S["grouped"], True)
+        else:
             ext.group_points_wrapper(b, 3, n, m, S["ns"], L["xyz_t"], S["idx"], S["grouped_xyz"])
             if L["c"]:
                 ext.group_points_wrapper(b, L["c"], n, m, S["ns"], L["features"], S["idx"], S["grouped_feat"])
 
+    def _group_level(self, L, cur_xyz, parity):
+        for S in L["scales"]:
+            self._query_scale(L, S, cur_xyz, parity)
+            self._group_scale(L, S, cur_xyz, parity)
+
+    def _side_stream(self, device):
+        if self.side is None:
+            self.side = torch.cuda.Stream(device=device)
+        return self.side
+
     def run(self, xyz):
         """xyz (B,N,3) contiguous fp32 on the stack's device; all outputs land in self.levels"""
-        b = self.batch
         main = torch.cuda.current_stream(xyz.device)
-        if self.overlap and self.side is None:
-            self.side = torch.cuda.Stream(device=xyz.device)
+        side = self._side_stream(xyz.device) if self.overlap else None
         cur_xyz = xyz
         for L in self.levels:
-            n, m = L["n"], L["m"]
-            L["xyz_t"].copy_(cur_xyz.transpose(1, 2))            # pointnet2_modules.py:30
-            L["temp"].fill_(1e10)                                # pointnet2_utils.py:26
-            ext.furthest_point_sampling_wrapper(b, n, m, cur_xyz, L["temp"], L["fps_idx"])
-            ext.gather_points_wrapper(b, 3, n, m, L["xyz_t"], L["fps_idx"], L["new_xyz_t"])
-            L["new_xyz"].copy_(L["new_xyz_t"].transpose(1, 2))   # pointnet2_modules.py:42-45
-            if self.overlap:
-                self.side.wait_stream(main)
-                with torch.cuda.stream(self.side):
-                    self._group_level(L, cur_xyz)
+            new_xyz = self._sample_level(L, cur_xyz, 0)
+            if side is not None:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    self._group_level(L, cur_xyz, 0)
             else:
-                self._group_level(L, cur_xyz)
-            cur_xyz = L["new_xyz"]
-        if self.overlap:
-            main.wait_stream(self.side)
+                self._group_level(L, cur_xyz, 0)
+            cur_xyz = new_xyz
+        if side is not None:
+            main.wait_stream(side)
         if self.with_fp:
-            # FP modules walk back up: unknown = xyz of the finer level, known = the coarser one
-            xyzs = [xyz] + [L["new_xyz"] for L in self.levels]
-            for k, F in enumerate(self.fp_bufs):
-                known = xyzs[len(self.levels) - k]
-                unknown = xyzs[len(self.levels) - k - 1]
-                ext.three_nn_wrapper(b, F["n"], F["m"], unknown, known, F["dist2"], F["idx"])
-                inv = 1.0 / (torch.sqrt(F["dist2"]) + 1e-8)      # pointnet2_modules.py:157-159
-                weight = inv / torch.sum(inv, dim=2, keepdim=True)
-                ext.three_interpolate_wrapper(b, F["c"], F["m"], F["n"], F["known_feats"], F["idx"], weight, F["out"])
+            self._run_fp(xyz, 0)
+
+    def run_pipelined(self, xyz, prev_xyz, parity):
+        """one steady-state step: stage S of this batch (into set `parity`) beside stage G of the previous
+        batch (`prev_xyz`, whose stage S filled set 1 - parity in the step before). (Splitting stage G further,
+        ball queries beside groupings on a third stream, was measured: no gain eagerly, a loss under a graph.)"""
+        main = torch.cuda.current_stream(xyz.device)
+        side = self._side_stream(xyz.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            cur = prev_xyz
+            for L in self.levels:
+                self._group_level(L, cur, 1 - parity)
+                cur = L["sets"][1 - parity]["new_xyz"]
+            if self.with_fp:
+                self._run_fp(prev_xyz, 1 - parity)
+        cur = xyz
+        for L in self.levels:
+            cur = self._sample_level(L, cur, parity)
+        main.wait_stream(side)
+
+    def _run_fp(self, xyz, parity):
+        b = self.batch
+        # FP modules walk back up: unknown = xyz of the finer level, known = the coarser one
+        xyzs = [xyz] + [L["sets"][parity]["new_xyz"] for L in self.levels]
+        for k, F in enumerate(self.fp_bufs):
+            known = xyzs[len(self.levels) - k]
+            unknown = xyzs[len(self.levels) - k - 1]
+            ext.three_nn_wrapper(b, F["n"], F["m"], unknown, known, F["dist2"], F["idx"])
+            inv = 1.0 / (torch.sqrt(F["dist2"]) + 1e-8)      # pointnet2_modules.py:157-159
+            weight = inv / torch.sum(inv, dim=2, keepdim=True)
+            ext.three_interpolate_wrapper(b, F["c"], F["m"], F["n"], F["known_feats"], F["idx"], weight, F["out"])
+
+    def _step_eager(self, k):
+        if self.pipelined:
+            self.run_pipelined(self.static_xyz, self.static_xyz, k & 1)
+        else:
+            self.run(self.static_xyz)
 
     def capture(self, xyz):
-        """capture run() into a HIP graph (torch.cuda.CUDAGraph); replay with self.replay()"""
+        """capture the step into HIP graph(s) (torch.cuda.CUDAGraph); replay with self.replay(). Pipelined:
+        two graphs, one per parity, replayed alternately."""
         self.static_xyz = xyz.clone()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            self.run(self.static_xyz)  # warm-up outside capture
+            for k in range(2):   # warm-up outside capture; fills both parities
+                self._step_eager(k)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.run(self.static_xyz)
-        return self.graph
+        self.graphs = []
+        for k in range(2 if self.pipelined else 1):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._step_eager(k)
+            self.graphs.append(g)
+        self.replays = 0
+        return self.graphs[0]
 
     def replay(self, xyz=None):
         if xyz is not None:
             self.static_xyz.copy_(xyz)
-        self.graph.replay()
+        self.graphs[self.replays % len(self.graphs)].replay()
+        self.replays += 1
+
+    def step(self, xyz):
+        """eager (no graph) step"""
+        if self.pipelined:
+            if self.static_xyz is None:
+                self.static_xyz = xyz
+                self.run_pipelined(xyz, xyz, 1)  # prime the other parity
+            self.run_pipelined(xyz, self.static_xyz, self.replays & 1)
+            self.replays += 1
+        else:
+            self.run(xyz)

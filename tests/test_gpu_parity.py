@@ -564,19 +564,49 @@ def test_ops_follow_the_current_stream_and_graph_replay(oracle):
     side.synchronize()
     np.testing.assert_array_equal(host(idx), oracle.furthest_point_sampling(xyz_h.numpy(), 512))
 
-    stack = sa_stack.SAStack(2, n=4096, device=DEV, npoints=(1024, 256, 64, 16), with_fp=False)
+    def outputs(stack, parity=0):
+        out = [host(L["fps_idx"]).copy() for L in stack.levels] + [host(S["idx"]).copy() for L in stack.levels for S in L["scales"]]
+        for L in stack.levels:
+            centre = L["sets"][parity]["new_xyz"].transpose(1, 2).unsqueeze(-1)
+            for S in L["scales"]:
+                if stack.fused:
+                    out.append(host(S["grouped"]).copy())
+                else:  # the reference composition: group xyz, subtract the centre, group features, concatenate
+                    parts = [S["grouped_xyz"] - centre] + ([S["grouped_feat"]] if S["grouped_feat"] is not None else [])
+                    out.append(host(torch.cat(parts, dim=1)).copy())
+        return out
+
+    kw = dict(n=4096, device=DEV, npoints=(1024, 256, 64, 16), with_fp=False, seed=3)
+    plain = sa_stack.SAStack(2, fused=False, shared_index=False, overlap=False, **kw)
+    plain.run(xyz)
+    torch.cuda.synchronize()
+    eager = outputs(plain)
+    # shared scene index + fused grouping, two streams, then the same from a HIP graph
+    stack = sa_stack.SAStack(2, **kw)
     stack.run(xyz)
     torch.cuda.synchronize()
-    eager = [host(L["fps_idx"]).copy() for L in stack.levels] + [host(S["idx"]).copy() for L in stack.levels for S in L["scales"]]
-    feats = [host(S["grouped_feat"]).copy() for L in stack.levels for S in L["scales"] if S["grouped_feat"] is not None]
+    for a, b in zip(eager, outputs(stack)):
+        np.testing.assert_array_equal(a, b)
     stack.capture(xyz)
     for L in stack.levels:
         L["fps_idx"].zero_()
+        for S in L["scales"]:
+            S["grouped"].zero_()
     stack.replay()
     torch.cuda.synchronize()
-    again = [host(L["fps_idx"]) for L in stack.levels] + [host(S["idx"]) for L in stack.levels for S in L["scales"]]
-    for a, b in zip(eager, again):
+    for a, b in zip(eager, outputs(stack)):
         np.testing.assert_array_equal(a, b)
-    for a, b in zip(feats, [host(S["grouped_feat"]) for L in stack.levels for S in L["scales"] if S["grouped_feat"] is not None]):
-        np.testing.assert_array_equal(a, b)
+    # software-pipelined: sampling of step k beside grouping of step k-1, two graphs replayed alternately
+    piped = sa_stack.SAStack(2, pipelined=True, **kw)
+    piped.capture(xyz)
+    for k in range(3):
+        for L in piped.levels:
+            L["fps_idx"].zero_()
+            for S in L["scales"]:
+                S["grouped"].zero_()
+                S["idx"].zero_()
+        piped.replay()
+        torch.cuda.synchronize()
+        for a, b in zip(eager, outputs(piped, parity=1 - (k & 1))):
+            np.testing.assert_array_equal(a, b)
     np.testing.assert_array_equal(eager[0], oracle.furthest_point_sampling(xyz_h.numpy(), 1024))
