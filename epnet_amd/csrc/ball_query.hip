@@ -119,7 +119,8 @@ constexpr int kIxThreads = 1024;
 constexpr int kIxMaxPoints = 65536;
 
 __global__ __launch_bounds__(kIxThreads) void bq_index_kernel(int n, int np, const float *__restrict__ xyz,
-                                                              float4 *__restrict__ sorted, float *__restrict__ boxes) {
+                                                              float4 *__restrict__ sorted, float *__restrict__ boxes,
+                                                              float *__restrict__ qboxes) {
     extern __shared__ int s_hist[];  // cell histogram / running offsets (spatial.h)
     __shared__ float s_box[6][16];
     __shared__ int s_part[16];
@@ -182,63 +183,157 @@ __global__ __launch_bounds__(kIxThreads) void bq_index_kernel(int n, int np, con
             bx[4] = any ? mn[2] : 3.0e38f; bx[5] = any ? mx[2] : 3.0e38f;
         }
     }
+    if (!qboxes) return;
+    // second level: one box per 4 consecutive buckets (256 sorted points)
+    qboxes += (size_t)blockIdx.x * (np / 256) * 6;
+    __threadfence_block();
+    __syncthreads();
+    for (int g = q; g < np / 256; g += kIxThreads) {
+        float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+        for (int k = 0; k < 4; ++k) {
+            const float *bx = boxes + (g * 4 + k) * 6;
+            if (bx[0] < 3.0e38f)  // not an all-padding bucket
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    mn[a] = fminf(mn[a], bx[2 * a]);
+                    mx[a] = fmaxf(mx[a], bx[2 * a + 1]);
+                }
+        }
+        const bool any = mn[0] <= mx[0];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            qboxes[g * 6 + 2 * a] = any ? mn[a] : 3.0e38f;
+            qboxes[g * 6 + 2 * a + 1] = any ? mx[a] : 3.0e38f;
+        }
+    }
 }
 
 constexpr int kQThreads = 256;
 
+// |clamp(c, box) - c|^2 < r^2, box = (min x, max x, min y, max y, min z, max z)
+__device__ __forceinline__ bool box_near(const float *__restrict__ bx, float cx, float cy, float cz, float radius2) {
+    const float2 bxx = *reinterpret_cast<const float2 *>(bx), byy = *reinterpret_cast<const float2 *>(bx + 2),
+                 bzz = *reinterpret_cast<const float2 *>(bx + 4);
+    const float px = __builtin_amdgcn_fmed3f(cx, bxx.x, bxx.y), py = __builtin_amdgcn_fmed3f(cy, byy.x, byy.y),
+                pz = __builtin_amdgcn_fmed3f(cz, bzz.x, bzz.y);
+    const float dx = cx - px, dy = cy - py, dz = cz - pz;
+    return (dx * dx + dy * dy + dz * dz) < radius2;
+}
+
+// One wave per centre. Two levels of boxes: the lanes test the quad boxes (256 points each), then -- 16 candidate
+// quads at a time -- the 4 bucket boxes of each candidate quad, then the 64 points of every near bucket. A ball holds
+// a handful of points (median 1-2 on KITTI-like scenes), so the hits are appended to a 64-entry list and ordered
+// by counting; only a ball with more than 64 hits takes the second pass through the N-bit bitmap.
 // DPL = bitmap dwords per lane = np / 2048 (np >= 2048)
 template <int DPL>
 __global__ __launch_bounds__(kQThreads) void bq_query_kernel(int np, int m, float radius2, int nsample,
                                                              const float *__restrict__ new_xyz,
                                                              const float4 *__restrict__ sorted,
-                                                             const float *__restrict__ boxes, int *__restrict__ idx) {
+                                                             const float *__restrict__ boxes,
+                                                             const float *__restrict__ qboxes, int *__restrict__ idx) {
     __shared__ unsigned s_bits[kQThreads / 64][64 * DPL];
+    __shared__ int s_quads[kQThreads / 64][64];
+    __shared__ int s_hits[kQThreads / 64][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int bs = blockIdx.y;
     const int ci = blockIdx.x * (kQThreads / 64) + wave;
     if (ci >= m) return;  // wave-uniform; no block-level barrier below
     sorted += (size_t)bs * np;
     boxes += (size_t)bs * (np / 64) * 6;
+    qboxes += (size_t)bs * (np / 256) * 6;
     const float *c = new_xyz + ((size_t)bs * m + ci) * 3;
     const float cx = c[0], cy = c[1], cz = c[2];
     int *out = idx + ((size_t)bs * m + ci) * nsample;
     unsigned *bits = s_bits[wave];
-#pragma unroll
-    for (int w = 0; w < DPL; ++w) bits[lane * DPL + w] = 0u;
+    int *quads = s_quads[wave], *hits = s_hits[wave];
 
-    const int nb = np >> 6;  // buckets, a multiple of 32 (np >= 2048)
-    for (int b0 = 0; b0 < nb; b0 += 64) {
-        const int b = b0 + lane;
-        bool near = false;
-        if (b < nb) {
-            const float *bx = boxes + b * 6;
-            const float px = __builtin_amdgcn_fmed3f(cx, bx[0], bx[1]), py = __builtin_amdgcn_fmed3f(cy, bx[2], bx[3]),
-                        pz = __builtin_amdgcn_fmed3f(cz, bx[4], bx[5]);
-            const float dx = cx - px, dy = cy - py, dz = cz - pz;
-            near = (dx * dx + dy * dy + dz * dz) < radius2;
+    const int nq = np >> 8;  // quads (>= 8)
+    int cnt = 0;             // hits so far (wave-uniform)
+    bool bitmap = false;
+    // the 64 points of one near bucket
+    auto scan_bucket = [&](int bb) {
+        const float4 p = sorted[(bb << 6) + lane];
+        const float dx = cx - p.x, dy = cy - p.y, dz = cz - p.z;
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        const bool hit = d2 < radius2;
+        if (!bitmap) {
+            const unsigned long long hm = __ballot(hit);
+            if (hm) {
+                const int pos = cnt + popc_below(hm);
+                if (hit && pos < 64) hits[pos] = __float_as_int(p.w);
+                cnt += (int)__popcll(hm);
+            }
+        } else if (hit) {
+            const int k = __float_as_int(p.w);
+            atomicOr(&bits[k >> 5], 1u << (k & 31));
         }
-        unsigned long long cand = __ballot(near);
-        while (cand) {
-            const int bb = b0 + (int)__builtin_ctzll(cand);
-            cand &= cand - 1ull;
-            const float4 p = sorted[(bb << 6) + lane];
-            const float dx = cx - p.x, dy = cy - p.y, dz = cz - p.z;
-            const float d2 = dx * dx + dy * dy + dz * dz;
-            if (d2 < radius2) {
-                const int k = __float_as_int(p.w);
-                atomicOr(&bits[k >> 5], 1u << (k & 31));
+    };
+    for (;;) {
+        cnt = 0;
+        if constexpr (DPL <= 2) {  // <= 64 buckets: one round over the bucket boxes, no second level
+            const bool bnear = lane < (np >> 6) && box_near(boxes + lane * 6, cx, cy, cz, radius2);
+            unsigned long long cand = __ballot(bnear);
+            while (cand) {
+                const int bb = (int)__builtin_ctzll(cand);
+                cand &= cand - 1ull;
+                scan_bucket(bb);
+            }
+        } else {
+            for (int q0 = 0; q0 < nq; q0 += 64) {
+                const int qd = q0 + lane;
+                const bool qnear = qd < nq && box_near(qboxes + qd * 6, cx, cy, cz, radius2);
+                const unsigned long long qmask = __ballot(qnear);
+                if (!qmask) continue;
+                const int nqc = (int)__popcll(qmask);
+                if (qnear) quads[popc_below(qmask)] = qd;
+                __builtin_amdgcn_wave_barrier();
+                for (int s0 = 0; s0 < nqc; s0 += 16) {
+                    const int slot = s0 + (lane >> 2);
+                    int bid = 0;
+                    bool bnear = false;
+                    if (slot < nqc) {
+                        bid = quads[slot] * 4 + (lane & 3);
+                        bnear = box_near(boxes + bid * 6, cx, cy, cz, radius2);
+                    }
+                    unsigned long long cand = __ballot(bnear);
+                    while (cand) {
+                        const int bb = __builtin_amdgcn_readlane(bid, (int)__builtin_ctzll(cand));
+                        cand &= cand - 1ull;
+                        scan_bucket(bb);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
             }
         }
+        if (bitmap || cnt <= 64) break;
+        bitmap = true;  // a crowded ball: second pass, every hit sets bit `original index`
+#pragma unroll
+        for (int w = 0; w < DPL; ++w) bits[lane * DPL + w] = 0u;
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    if (!bitmap) {
+        // order the <= 64 hits by original index: rank = number of smaller indices (they are distinct)
+        __builtin_amdgcn_wave_barrier();
+        const int mine = lane < cnt ? hits[lane] : 0x7fffffff;
+        int rank = 0;
+        for (int j = 0; j < cnt; ++j) rank += __builtin_amdgcn_readlane(mine, j) < mine ? 1 : 0;
+        if (lane < cnt && rank < nsample) out[rank] = mine;
+        // padding with the first hit (ball_query_gpu.cu:35-39); an empty ball is all zeros
+        int first = 0;
+        if (cnt) first = __builtin_amdgcn_readlane(mine, (int)__builtin_ctzll(__ballot(lane < cnt && rank == 0)));
+        for (int l = cnt + lane; l < nsample; l += 64) out[l] = first;
+        return;
     }
     // read the bitmap back in index order: lane l owns bits [l*32*DPL, (l+1)*32*DPL)
-    int cnt = 0;
+    int bc = 0;
 #pragma unroll 8
-    for (int i = 0; i < DPL; ++i) cnt += __popc(bits[lane * DPL + i]);
-    const int incl = wave_inclusive_scan(cnt);
+    for (int i = 0; i < DPL; ++i) bc += __popc(bits[lane * DPL + i]);
+    const int incl = wave_inclusive_scan(bc);
     const int total = __builtin_amdgcn_readlane(incl, 63);
-    int pos = incl - cnt;
+    int pos = incl - bc;
     int mine_first = 0x7fffffff;
-    if (cnt > 0 && (pos < nsample || pos == 0)) {
+    if (bc > 0 && (pos < nsample || pos == 0)) {
         for (int i = 0; i < DPL; ++i) {
             unsigned ww = bits[lane * DPL + i];
             if (ww && mine_first == 0x7fffffff) mine_first = (lane * DPL + i) * 32 + (int)__builtin_ctz(ww);
@@ -250,8 +345,7 @@ __global__ __launch_bounds__(kQThreads) void bq_query_kernel(int np, int m, floa
             if (pos >= nsample) break;
         }
     }
-    // padding with the first hit (ball_query_gpu.cu:35-39); an empty ball is all zeros
-    const unsigned long long have = __ballot(cnt > 0);
+    const unsigned long long have = __ballot(bc > 0);
     int first = 0;
     if (have) first = __builtin_amdgcn_readlane(mine_first, (int)__builtin_ctzll(have));
     for (int l = total + lane; l < nsample; l += 64) out[l] = first;
@@ -286,22 +380,25 @@ static size_t bq_index_lds(int) { return (size_t)(kCells + kCells / (kCells / kI
 
 // shared with three_nn (interpolate.hip): cell-sorted float4 copy (x, y, z, original index) of n points padded
 // to np (a multiple of 64) per scene, plus one box (6 floats) per 64 sorted points
-int epnet::spatial_index_launch(int b, int n, int np, const float *xyz, float4 *sorted, float *boxes, hipStream_t s) {
-    hipLaunchKernelGGL(bq_index_kernel, dim3(b), dim3(kIxThreads), bq_index_lds(np), s, n, np, xyz, sorted, boxes);
+int epnet::spatial_index_launch(int b, int n, int np, const float *xyz, float4 *sorted, float *boxes, float *qboxes,
+                                hipStream_t s) {
+    hipLaunchKernelGGL(bq_index_kernel, dim3(b), dim3(kIxThreads), bq_index_lds(np), s, n, np, xyz, sorted, boxes, qboxes);
     return check_launch("spatial index");
 }
 
 static int bq_query_launch(int b, int np, int m, float radius, int nsample, const float *new_xyz, const float4 *sorted,
-                           const float *boxes, int *idx, hipStream_t s) {
+                           int *idx, hipStream_t s) {
+    const float *boxes = (const float *)(sorted + (size_t)b * np);
+    const float *qboxes = boxes + (size_t)b * (np / 64) * 6;
     const float radius2 = radius * radius;  // ball_query_gpu.cu:23
     dim3 grid(div_up(m, kQThreads / 64), b);
     switch (np / 2048) {
-        case 1: hipLaunchKernelGGL(bq_query_kernel<1>, grid, dim3(kQThreads), 0, s, np, m, radius2, nsample, new_xyz, sorted, boxes, idx); break;
-        case 2: hipLaunchKernelGGL(bq_query_kernel<2>, grid, dim3(kQThreads), 0, s, np, m, radius2, nsample, new_xyz, sorted, boxes, idx); break;
-        case 4: hipLaunchKernelGGL(bq_query_kernel<4>, grid, dim3(kQThreads), 0, s, np, m, radius2, nsample, new_xyz, sorted, boxes, idx); break;
-        case 8: hipLaunchKernelGGL(bq_query_kernel<8>, grid, dim3(kQThreads), 0, s, np, m, radius2, nsample, new_xyz, sorted, boxes, idx); break;
-        case 16: hipLaunchKernelGGL(bq_query_kernel<16>, grid, dim3(kQThreads), 0, s, np, m, radius2, nsample, new_xyz, sorted, boxes, idx); break;
-        default: hipLaunchKernelGGL(bq_query_kernel<32>, grid, dim3(kQThreads), 0, s, np, m, radius2, nsample, new_xyz, sorted, boxes, idx); break;
+        case 1: hipLaunchKernelGGL(bq_query_kernel<1>, grid, dim3(kQThreads), 0, s, np, m, radius2, nsample, new_xyz, sorted, boxes, qboxes, idx); break;
+        case 2: hipLaunchKernelGGL(bq_query_kernel<2>, grid, dim3(kQThreads), 0, s, np, m, radius2, nsample, new_xyz, sorted, boxes, qboxes, idx); break;
+        case 4: hipLaunchKernelGGL(bq_query_kernel<4>, grid, dim3(kQThreads), 0, s, np, m, radius2, nsample, new_xyz, sorted, boxes, qboxes, idx); break;
+        case 8: hipLaunchKernelGGL(bq_query_kernel<8>, grid, dim3(kQThreads), 0, s, np, m, radius2, nsample, new_xyz, sorted, boxes, qboxes, idx); break;
+        case 16: hipLaunchKernelGGL(bq_query_kernel<16>, grid, dim3(kQThreads), 0, s, np, m, radius2, nsample, new_xyz, sorted, boxes, qboxes, idx); break;
+        default: hipLaunchKernelGGL(bq_query_kernel<32>, grid, dim3(kQThreads), 0, s, np, m, radius2, nsample, new_xyz, sorted, boxes, qboxes, idx); break;
     }
     return check_launch("ball_query query");
 }
@@ -317,7 +414,8 @@ extern "C" int epnet_scene_index_build(int b, int n, const float *xyz, void *ind
     EPNET_REQUIRE(b <= 65535);
     const int np = scene_index_np(n);
     float4 *sorted = (float4 *)index;
-    return spatial_index_launch(b, n, np, xyz, sorted, (float *)(sorted + (size_t)b * np), (hipStream_t)stream);
+    float *boxes = (float *)(sorted + (size_t)b * np);
+    return spatial_index_launch(b, n, np, xyz, sorted, boxes, boxes + (size_t)b * (np / 64) * 6, (hipStream_t)stream);
 }
 
 extern "C" int epnet_ball_query_indexed(int b, int n, int m, float radius, int nsample, const float *new_xyz,
@@ -330,9 +428,7 @@ extern "C" int epnet_ball_query_indexed(int b, int n, int m, float radius, int n
     if (index_bytes < need) return EPNET_ENOMEM;
     EPNET_REQUIRE(b <= 65535);
     const int np = scene_index_np(n);
-    const float4 *sorted = (const float4 *)index;
-    return bq_query_launch(b, np, m, radius, nsample, new_xyz, sorted, (const float *)(sorted + (size_t)b * np), idx,
-                           (hipStream_t)stream);
+    return bq_query_launch(b, np, m, radius, nsample, new_xyz, (const float4 *)index, idx, (hipStream_t)stream);
 }
 
 extern "C" size_t epnet_ball_query_workspace_bytes(int b, int n, int m) {

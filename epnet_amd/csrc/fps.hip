@@ -389,6 +389,9 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
     if (q == 0) s_idx[0] = 0;  // rank 0 == point 0
     __syncthreads();
 
+    // a strictly serial chain: when it shares a SIMD with a wide kernel (software-pipelined SA stack), every
+    // instruction it has ready should issue first
+    __builtin_amdgcn_s_setprio(3);
     EPNET_STATS_BEGIN;
     EPNET_STAMP(t_loop0);
     // this wave's best point, recomputed only in rounds that changed one of its buckets

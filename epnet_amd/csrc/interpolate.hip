@@ -497,7 +497,7 @@ extern "C" int epnet_three_nn_ws(int b, int n, int m, const float *unknown, cons
     const int np = nn_padded(m);
     float4 *sorted = (float4 *)workspace;
     float *boxes = (float *)(sorted + (size_t)b * np);
-    int rc = spatial_index_launch(b, m, np, known, sorted, boxes, s);
+    int rc = spatial_index_launch(b, m, np, known, sorted, boxes, nullptr, s);
     if (rc) return rc;
     dim3 grid(div_up(n, kNnIxThreads / 64), b);
     hipLaunchKernelGGL(three_nn_indexed_kernel, grid, dim3(kNnIxThreads), 0, s, n, m, np, unknown, sorted, boxes, dist2, idx);

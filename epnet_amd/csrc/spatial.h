@@ -199,6 +199,7 @@ int csr_build_launch(int b, int n, int p, const int *idx, int *offsets, int *per
 // ---- scene index: caller scratch shared by FPS, ball query and three_nn of one level ---------------------
 // per scene: the points counting-sorted by cell as float4 (x, y, z, original index; padding = 3e38 / -1),
 // padded to np = a power of two >= 2048, followed (after all scenes) by one box (6 floats) per 64 sorted points
+// ("bucket") and then one box per 256 sorted points ("quad")
 inline int scene_index_np(int n) {
     int np = 2048;
     while (np < n) np <<= 1;
@@ -207,10 +208,12 @@ inline int scene_index_np(int n) {
 inline size_t scene_index_bytes(int b, int n) {
     if (b <= 0 || n <= 1024 || n > 65536) return 0;
     const size_t np = (size_t)scene_index_np(n);
-    return (size_t)b * (np * sizeof(float4) + (np / 64) * 6 * sizeof(float));
+    return (size_t)b * (np * sizeof(float4) + (np / 64 + np / 256) * 6 * sizeof(float));
 }
 
 // defined in ball_query.hip
-int spatial_index_launch(int b, int n, int np, const float *xyz, float4 *sorted, float *boxes, hipStream_t s);
+// qboxes (one box per 4 buckets) may be NULL
+int spatial_index_launch(int b, int n, int np, const float *xyz, float4 *sorted, float *boxes, float *qboxes,
+                         hipStream_t s);
 
 }  // namespace epnet
