@@ -432,7 +432,7 @@ extern "C" int epnet_ball_query_indexed(int b, int n, int m, float radius, int n
 }
 
 extern "C" size_t epnet_ball_query_workspace_bytes(int b, int n, int m) {
-    if (n < 2048 || m <= 0) return 0;  // small or huge scenes: direct scan, no scratch
+    if (n < 1024 || m <= 0) return 0;  // small or huge scenes: direct scan, no scratch
     return scene_index_bytes(b, n);
 }
 

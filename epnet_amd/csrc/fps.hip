@@ -767,7 +767,8 @@ extern "C" int epnet_furthest_point_sampling_indexed(int b, int n, int m, const 
                                                      size_t index_bytes, float *temp, int *idx,
                                                      epnet_stream_t stream) {
     const size_t need = scene_index_bytes(b, n);
-    if (need == 0 || !index || n > 16384 || m <= 1)
+    // n <= 1024: the reference block size (hence the tie-break rank) depends on n; the one-wave kernel handles it
+    if (need == 0 || !index || n <= 1024 || n > 16384 || m <= 1)
         return epnet_furthest_point_sampling(b, n, m, xyz, temp, idx, stream);
     EPNET_REQUIRE(idx);
     if (index_bytes < need) return EPNET_ENOMEM;

@@ -163,6 +163,28 @@ __global__ __launch_bounds__(kGThreads) void group_xyz_centred_kernel(int n, int
     dst[(size_t)p * 2] = pt[2] - ce[2];
 }
 
+// the same for 4 consecutive samples of one centre per thread (nsample % 4 == 0): one 16-B index load, three 16-B stores
+__global__ __launch_bounds__(kGThreads) void group_xyz_centred_vec4_kernel(int n, int npoints, int nsample, size_t ostride,
+                                                                           const float *__restrict__ xyz,
+                                                                           const float *__restrict__ new_xyz,
+                                                                           const int *__restrict__ idx,
+                                                                           float *__restrict__ out) {
+    const int bs = blockIdx.y;
+    const int p = npoints * nsample;
+    const int q = (blockIdx.x * kGThreads + threadIdx.x) * 4;
+    if (q >= p) return;
+    const int4 id = *reinterpret_cast<const int4 *>(idx + (size_t)bs * p + q);
+    const float *base = xyz + (size_t)bs * n * 3;
+    const float *ce = new_xyz + ((size_t)bs * npoints + q / nsample) * 3;
+    const float cx = ce[0], cy = ce[1], cz = ce[2];
+    const float *p0 = base + (size_t)id.x * 3, *p1 = base + (size_t)id.y * 3, *p2 = base + (size_t)id.z * 3,
+                *p3 = base + (size_t)id.w * 3;
+    float *dst = out + (size_t)bs * ostride + q;
+    *reinterpret_cast<float4 *>(dst) = make_float4(p0[0] - cx, p1[0] - cx, p2[0] - cx, p3[0] - cx);
+    *reinterpret_cast<float4 *>(dst + (size_t)p) = make_float4(p0[1] - cy, p1[1] - cy, p2[1] - cy, p3[1] - cy);
+    *reinterpret_cast<float4 *>(dst + (size_t)p * 2) = make_float4(p0[2] - cz, p1[2] - cz, p2[2] - cz, p3[2] - cz);
+}
+
 static int launch_gather_rows(int b, int c, int n, long long p, const float *points, const int *idx, float *out,
                               hipStream_t s, const char *what, size_t ostride = 0) {
     if (ostride == 0) ostride = (size_t)c * (size_t)p;
@@ -395,8 +417,12 @@ extern "C" int epnet_group_concat(int b, int c, int n, int npoints, int nsample,
     const int ch0 = use_xyz ? 3 : 0;
     const size_t ostride = (size_t)(ch0 + c) * (size_t)p;
     if (use_xyz) {
-        hipLaunchKernelGGL(group_xyz_centred_kernel, dim3((unsigned)div_up64(p, kGThreads), b), dim3(kGThreads), 0, s, n, npoints,
-                           nsample, ostride, xyz, new_xyz, idx, out);
+        if (nsample % 4 == 0 && (((uintptr_t)idx | (uintptr_t)out) % 16 == 0) && (ostride % 4 == 0))
+            hipLaunchKernelGGL(group_xyz_centred_vec4_kernel, dim3((unsigned)div_up64(p / 4, kGThreads), b), dim3(kGThreads), 0,
+                               s, n, npoints, nsample, ostride, xyz, new_xyz, idx, out);
+        else
+            hipLaunchKernelGGL(group_xyz_centred_kernel, dim3((unsigned)div_up64(p, kGThreads), b), dim3(kGThreads), 0, s, n,
+                               npoints, nsample, ostride, xyz, new_xyz, idx, out);
         int rc = check_launch("group_concat xyz");
         if (rc) return rc;
     }

@@ -206,7 +206,7 @@ inline int scene_index_np(int n) {
     return np;
 }
 inline size_t scene_index_bytes(int b, int n) {
-    if (b <= 0 || n <= 1024 || n > 65536) return 0;
+    if (b <= 0 || n < 1024 || n > 65536) return 0;
     const size_t np = (size_t)scene_index_np(n);
     return (size_t)b * (np * sizeof(float4) + (np / 64 + np / 256) * 6 * sizeof(float));
 }

@@ -133,7 +133,7 @@ def scene_index_bytes(b, n):
 
 def scene_index(xyz):
     """one spatial sort of (B,N,3) points, shared by the sampling and the ball queries of an SA level; None where
-    the library indexes nothing (N <= 1024 or N > 65536). include/epnet_ops.h: epnet_scene_index_build"""
+    the library indexes nothing (N < 1024 or N > 65536). include/epnet_ops.h: epnet_scene_index_build"""
     b, n = xyz.shape[0], xyz.shape[1]
     l = _lib.lib()
     nbytes = l.epnet_scene_index_bytes(b, n)

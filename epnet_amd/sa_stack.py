@@ -19,6 +19,8 @@ The stack has two stages with very different machine behaviour:
 ``pipelined=True`` runs S of batch k beside G of batch k-1 (double-buffered centres / indices), so that in
 steady state a step costs max(S, G) instead of S(level 1) + G.
 """
+import os
+
 import torch
 
 from . import pointnet2_cuda as ext
@@ -71,6 +73,7 @@ class SAStack:
         self.fused = fused                # grouped [xyz - centre ; features] from one kernel (epnet_group_concat)
         self.shared_index = shared_index  # one scene index per level for FPS + both ball queries
         self.pipelined = pipelined
+        self.tail_scales = int(os.environ.get("EPNET_SA_TAIL_SCALES", "0"))
         self.side = None
         self.npoints, self.radii, self.nsamples, self.feat_channels = npoints, radii, nsamples, feat_channels
         self.with_fp, self.fp = with_fp, fp
@@ -122,10 +125,10 @@ class SAStack:
             self.static_prev = [None, None]
 
     # ---- stage S: the sampling chain of one level
-    def _sample_level(self, L, cur_xyz, parity):
+    def _sample_level(self, L, cur_xyz, parity, index_built=False):
         b, n, m = self.batch, L["n"], L["m"]
         P = L["sets"][parity]
-        if P["index"] is not None:
+        if P["index"] is not None and not index_built:
             ext.scene_index_build_wrapper(b, n, cur_xyz, P["index"])
         L["xyz_t"].copy_(cur_xyz.transpose(1, 2))            # pointnet2_modules.py:30
         L["temp"].fill_(1e10)                                # pointnet2_utils.py:26
@@ -191,17 +194,40 @@ class SAStack:
         ball queries beside groupings on a third stream, was measured: no gain eagerly, a loss under a graph.)"""
         main = torch.cuda.current_stream(xyz.device)
         side = self._side_stream(xyz.device)
+        # the level-1 scene index of this batch goes first: it is a one-workgroup-per-scene kernel that cannot
+        # find a free CU once the wide stage-G kernels are in flight
+        first = self.levels[0]
+        if first["sets"][parity]["index"] is not None:
+            ext.scene_index_build_wrapper(self.batch, first["n"], xyz, first["sets"][parity]["index"])
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            cur = prev_xyz
-            for L in self.levels:
-                self._group_level(L, cur, 1 - parity)
-                cur = L["sets"][1 - parity]["new_xyz"]
+            # order inside stage G: everything of the previous batch's stage S is complete, so only "ball query
+            # before its grouping" binds. The level-1 FPS of stage S holds ~80 % of every CU's vector registers
+            # for the first 2.5 ms of the step: the LDS-staged feature gathers of levels 2-4 (few registers) run
+            # beside it, the level-1 ball queries (occupancy-hungry) after it.
+            inputs = [prev_xyz] + [L["sets"][1 - parity]["new_xyz"] for L in self.levels[:-1]]
+            deep = list(zip(self.levels, inputs))[1:]
+            for k, (L, cur) in enumerate(deep):
+                if k == 0:       # level 2 (indexed queries: few registers) then its gathers beside the level-1 FPS
+                    self._group_level(L, cur, 1 - parity)
+            for L, cur in deep[1:]:
+                for S in L["scales"]:
+                    self._query_scale(L, S, cur, 1 - parity)
+            for L, cur in deep[1:]:
+                for S in L["scales"]:
+                    self._group_scale(L, S, cur, 1 - parity)
+            for S in first["scales"][self.tail_scales:]:
+                self._query_scale(first, S, prev_xyz, 1 - parity)
+                self._group_scale(first, S, prev_xyz, 1 - parity)
             if self.with_fp:
                 self._run_fp(prev_xyz, 1 - parity)
         cur = xyz
         for L in self.levels:
-            cur = self._sample_level(L, cur, parity)
+            cur = self._sample_level(L, cur, parity, index_built=L is first)
+        # if the sampling chain is the shorter stage it can take level-1 scales of stage G as its tail
+        for S in first["scales"][:self.tail_scales]:
+            self._query_scale(first, S, prev_xyz, 1 - parity)
+            self._group_scale(first, S, prev_xyz, 1 - parity)
         main.wait_stream(side)
 
     def _run_fp(self, xyz, parity):

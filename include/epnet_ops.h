@@ -145,7 +145,7 @@ int epnet_three_interpolate_grad_ws(int b, int c, int n, int m, const float *gra
                                     epnet_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------
- * scene index: one spatial sort of a level's points (1024 < n <= 65536), built once in caller scratch and
+ * scene index: one spatial sort of a level's points (1024 <= n <= 65536), built once in caller scratch and
  * shared by the sampling and both ball queries of that level (the reference has no counterpart: every one of
  * its kernels scans all n points). Results are identical to the plain entry points.
  * epnet_scene_index_bytes returns 0 where no index applies; the *_indexed entry points then (or with

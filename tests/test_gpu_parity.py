@@ -113,6 +113,7 @@ def test_fps_full_size_properties():
 @pytest.mark.parametrize("b,n,m,kind", [
     (2, 16384, 4096, "kitti"), (2, 16384, 300, "dup"), (2, 8192, 700, "kitti"), (3, 4096, 1024, "kitti"),
     (2, 2048, 512, "ubox"), (2, 1025, 64, "kitti"), (2, 1500, 1499, "dup"), (2, 10000, 33, "ubox"),
+    (2, 1024, 256, "kitti"),     # indexed for the ball queries only: sampling takes the one-wave kernel
     (2, 900, 100, "kitti"),      # below the indexed range: index is None, plain path
     (1, 20000, 20, "kitti"),     # index exists (ball query uses it) but sampling falls back above 16384
 ])
@@ -122,7 +123,7 @@ def test_fps_over_scene_index_matches_oracle(oracle, b, n, m, kind):
     xyz = rand_cloud(b, n, seed=300 + n, kind=kind)
     d_xyz = dev(xyz)
     index = ext.scene_index(d_xyz)
-    assert (index is None) == (n <= 1024)
+    assert (index is None) == (n < 1024)
     temp = torch.full((b, n), 1e10, device=DEV)
     idx = torch.empty((b, m), dtype=torch.int32, device=DEV)
     ext.furthest_point_sampling_indexed_wrapper(b, n, m, d_xyz, index, temp, idx)
@@ -536,6 +537,11 @@ def test_query_and_group_fused_equals_reference_composition():
             (fused * w).sum().backward()
             (ref * w).sum().backward()
             np.testing.assert_allclose(host(f1.grad), host(f2.grad), rtol=1e-5, atol=1e-5)
+    # nsample not a multiple of 4: the scalar centred-xyz kernel
+    fused = p2u.QueryAndGroup(0.8, 7)(xyz, new_xyz, feats)
+    idx = p2u.ball_query(0.8, 7, xyz, new_xyz)
+    gx = p2u.grouping_operation(xyz.transpose(1, 2).contiguous(), idx) - new_xyz.transpose(1, 2).unsqueeze(-1)
+    assert torch.equal(fused, torch.cat([gx, p2u.grouping_operation(feats, idx)], dim=1))
     # a gradient w.r.t. the coordinates takes the unfused, fully differentiable path
     xr = xyz.clone().requires_grad_(True)
     out = p2u.QueryAndGroup(0.8, 16)(xr, new_xyz, feats)
