@@ -1,20 +1,23 @@
 #!/usr/bin/env python3
 """bench.py -- SA-stack points/s per GPU on synthetic KITTI-shaped scenes (BASELINE.json's metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--kind kitti|ubox|dup] [--no-graph]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--pipelined 0|1] [--kind kitti|ubox|dup] [--no-graph]
 
-One "step" = one pass of the 4-level set-abstraction OPERATOR stack (4 FPS + 4 gather + 8 ball_query +
-14 grouping calls, epnet_amd/sa_stack.py) over a batch of B independent 16384-point scenes that are
-already resident in HBM. N > 1: launched by torch.distributed.run, one rank per GPU; every rank owns its
-own scenes (different seeds), there is NO collective in the data path (the ops are independent per
-scene), so scaling is "weak". Timing: barrier + synchronize on both sides of exactly K steps, MAX over
-ranks; rank 0 prints ONE JSON line.
+One "step" = one pass of the 4-level set-abstraction OPERATOR stack (per level: scene index, FPS, gather, two
+ball queries, two fused groupings -- epnet_amd/sa_stack.py) over a batch of B independent 16384-point scenes
+that are already resident in HBM (default B = 256: 12.5 GB of resident buffers out of 288 GB). Steps are
+software-pipelined by default: the latency-bound sampling chain of step k runs beside the bandwidth-bound
+ball query + grouping of step k-1 (double-buffered centres / indices), every step does the full work of one
+batch; --pipelined 0 runs every step on its own (the latency figure). N > 1: launched by
+torch.distributed.run, one rank per GPU; every rank owns its own scenes (different seeds), there is NO
+collective in the data path (the ops are independent per scene), so scaling is "weak". Timing: barrier +
+synchronize on both sides of exactly K steps, MAX over ranks; rank 0 prints ONE JSON line.
 
 Extra objects on that line:
-  roofline      the kernel with the largest share of the step (furthest point sampling), priced by its
-                ALGORITHMIC bytes per launch / its average duration measured with HIP events on the
-                launch stream over an instrumented replay of the same K steps; `kernels` lists the same
-                figure for every op family (the grouping kernels are the bandwidth-bound ones).
+  roofline      the op with the largest share of the step, priced by its ALGORITHMIC bytes per launch / its
+                average duration measured with HIP events on the launch stream over an instrumented
+                (unpipelined, single-stream) run of the same K steps; `kernels` lists the same figure for every
+                op family, `roofline_hbm_bound` repeats it for the largest bandwidth-bound one (the grouping).
   cpu_baseline  the CPU oracle (a scalar C port of the reference kernels, 1 core) timed on this host on
                 a bounded sample of the same workload.
 """
@@ -36,7 +39,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("EPNET_BENCH_BATCH", "16")),
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("EPNET_BENCH_BATCH", "256")),
                     help="scenes per GPU per step")
     ap.add_argument("--points", type=int, default=16384)
     ap.add_argument("--kind", default="kitti", choices=["kitti", "ubox", "dup"])
@@ -138,7 +141,8 @@ def op_family(name, head):
         return ("group_xyz" if c == 3 else "group_feat"), b * (m * ns * 4 + c * n * 4 + c * m * ns * 4)
     if name.startswith("group_concat_w"):  # the two grouping calls + centre subtraction + concat of the reference, one output
         b, c, n, m, ns = head[:5]
-        return "group", b * (m * ns * 4 + 3 * n * 4 + 3 * m * ns * 4) + (b * (m * ns * 4 + c * n * 4 + c * m * ns * 4) if c else 0)
+        xyz_part = b * (m * ns * 4 + 3 * n * 4 + 3 * m * ns * 4)
+        return ("group", xyz_part + b * (m * ns * 4 + c * n * 4 + c * m * ns * 4)) if c else ("group_xyz", xyz_part)
     if name.startswith("three_nn"):
         b, n, m = head[:3]
         return "three_nn", b * (n * 12 + m * 12 + n * 24)
@@ -148,15 +152,27 @@ def op_family(name, head):
     return name, 0
 
 
+# kernels behind each op family (rocprofv3 names), for the PMC lookup and for the reader of the JSON line
+FAMILY_KERNELS = {
+    "fps N=16384 M=4096": ["epnet::pruned::fps_indexed_kernel<8, 32>"],
+    "fps N=4096 M=1024": ["epnet::pruned::fps_indexed_kernel<4, 16>"],
+    "group": ["epnet::group_xyz_centred_vec4_kernel", "epnet::gather_rows_lds_kernel"],
+    "group_xyz": ["epnet::group_xyz_centred_vec4_kernel"],
+    "scene_index N=16384": ["epnet::bq_index_kernel"],
+}
+PMC_PROFILE = os.path.join("profiles", "r01_pmc_traffic.json")
+
+
 def pmc_traffic(family, args):
-    """HBM bytes per launch of the dominant kernel from the committed PMC profile (collected at 16 kitti
-    scenes per launch; per-scene figure x scenes). None when no matching profile exists."""
-    symbol = {"fps N=16384 M=4096": "epnet::pruned::fps_pruned_kernel<8, 32>"}.get(family)
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if symbol is None or args.kind != "kitti" or args.points != 16384 or not os.path.exists(path):
+    """HBM bytes per launch of an op family from the committed PMC profile (two --pmc passes of this bench with every
+    kernel alone on the device, profiles/collect.sh + profiles/summarize.py), scaled by scenes per launch.
+    None when no matching profile exists."""
+    path = os.path.join(ROOT, PMC_PROFILE)
+    if args.kind != "kitti" or args.points != 16384 or not os.path.exists(path):
         return None
-    k = json.load(open(path))["kernels"].get(symbol)
-    return None if k is None else int(k["hbm_bytes_avg"] / 16 * args.batch)
+    prof = json.load(open(path))
+    k = prof.get("families", {}).get(family)
+    return None if k is None else int(k["hbm_bytes_avg"] / prof["scenes_per_launch"] * args.batch)
 
 
 def main():
@@ -233,15 +249,22 @@ def main():
         kernels[label] = {"launches_per_step": f["launches"] // args.steps, "avg_ms": round(avg_ms, 5),
                           "step_ms": round(f["ms"] / args.steps, 5),
                           "bytes_per_launch": f["bytes"] // f["launches"], "GBps": round(gbs, 2)}
+    def roof(label, note):
+        k = kernels[label]
+        traffic = pmc_traffic(label, args)
+        return {"bound": "hbm", "kernel": label, "kernel_symbols": FAMILY_KERNELS.get(label), "achieved": k["GBps"],
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(k["GBps"] / HBM_PEAK_GBS, 6), "traffic": traffic,
+                "traffic_source": (PMC_PROFILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, scaled by scenes per launch)")
+                if traffic else None, "avg_launch_ms": k["avg_ms"], "note": note}
+
     dominant = max(kernels, key=lambda k: kernels[k]["step_ms"])
-    dk = kernels[dominant]
-    traffic = pmc_traffic(dominant, args)
-    roofline = {"bound": "hbm", "kernel": dominant, "achieved": dk["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(dk["GBps"] / HBM_PEAK_GBS, 6), "traffic": traffic,
-                "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at 16 scenes, "
-                                  "scaled by scenes per launch)" if traffic else None,
-                "note": "FPS is a chain of M-1 dependent arg-max iterations per scene (latency bound), one workgroup "
-                        "per scene; the bandwidth-bound kernels are group_feat/group_xyz, see 'kernels'"}
+    fps_note = ("FPS is a chain of M-1 dependent arg-max rounds per scene (latency bound, one workgroup per scene, ~0.6 us per "
+                "round): its HBM fraction is tiny by construction; see roofline_hbm_bound for the bandwidth-bound kernel")
+    grp_note = ("grouping = [grouped xyz - centre ; grouped features] of one MSG scale (epnet_group_concat): random reads from "
+                "LDS-staged rows, 16-byte coalesced writes; write-only ceiling of this grid measured at 6.2 TB/s")
+    roofline = roof(dominant, fps_note if dominant.startswith("fps") else grp_note)
+    hbm_label = max((k for k in kernels if not k.startswith("fps")), key=lambda k: kernels[k]["step_ms"])
+    roofline_hbm = roof(hbm_label, grp_note if hbm_label.startswith("group") else "")
     stack_bytes = sa_stack.sa_algorithmic_bytes(args.points)["total"] + (sa_stack.fp_algorithmic_bytes()["total"] if args.with_fp else 0)
     stack_gbs = (value / args.points) * stack_bytes / 1e9 / world
 
@@ -261,14 +284,14 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%d x %d-pt %s scenes per GPU per step through the 4-level SA op stack "
-                                   "(4 FPS + 4 gather + 8 ball_query + 14 grouping%s), pyramid 16384>4096>1024>256>64, "
+                                   "(4 FPS + 4 gather + 8 ball_query + 8 fused groupings [xyz - centre ; features]%s), pyramid 16384>4096>1024>256>64, "
                                    "radii [[.1,.5],[.5,1],[1,2],[2,4]], nsample [16,32], C=0/96/256/512, %s launch"
                                    % (args.batch, args.points, args.kind, " + 4 three_nn + 4 three_interpolate" if args.with_fp else "",
                                       "eager" if args.no_graph else "HIP-graph"),
                        "scenes_per_gpu": args.batch, "software_pipelined": bool(args.pipelined), "points_per_scene": args.points, "parallelism": "scene-parallel x%d" % world},
             "points_per_s_per_gpu": round(value / world, 1),
             "stack_algorithmic_GBps_per_gpu": round(stack_gbs, 2), "stack_hbm_frac": round(stack_gbs / HBM_PEAK_GBS, 6),
-            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+            "roofline": roofline, "roofline_hbm_bound": roofline_hbm, "kernels": kernels, "cpu_baseline": cpu,
         }
         if sweep:
             line["sweep"] = sweep

@@ -1,0 +1,32 @@
+#!/bin/bash
+# Collects the round's measurement evidence on the GPU box (run through gpurun from the repo root):
+#   1. the default bench line (software-pipelined, HIP graph) and the same command under rocprofv3 --kernel-trace --stats
+#   2. rocprofv3 --kernel-trace --stats of the UNOVERLAPPED run (`--pipelined 0 --no-overlap --no-graph`: every kernel
+#      alone on the device, the execution bench.py's per-kernel HIP-event numbers come from) + per-family table
+#   3. two PMC passes (FETCH_SIZE, WRITE_SIZE; --kernel-trace only) of the unoverlapped run + per-family HBM bytes
+# usage: bash profiles/collect.sh TAG      -> gpurun_out/prof_TAG/*  (copy what should be judged into profiles/)
+set -e
+TAG=${1:-r01}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
+rm -rf $OUT && mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+python3 bench.py > $OUT/bench.json
+echo "bench done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_default -- python3 bench.py --cpu-scenes 0 > $OUT/bench_under_rocprof.json
+cp $(find $OUT/stats_default -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_default.csv
+echo "default stats pass done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_alone -- python3 bench.py --cpu-scenes 0 --pipelined 0 --no-overlap --no-graph > $OUT/bench_alone_under_rocprof.json
+cp $(find $OUT/stats_alone -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_alone.csv
+python3 profiles/summarize.py trace $(find $OUT/stats_alone -name "*kernel_trace.csv" | head -1) $OUT/family_durations_alone.json
+echo "unoverlapped stats pass done"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --cpu-scenes 0 --pipelined 0 --no-overlap --no-graph > $OUT/pmc_fetch.log
+echo "fetch pass done"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 2 --warmup 1 --cpu-scenes 0 --pipelined 0 --no-overlap --no-graph > $OUT/pmc_write.log
+echo "write pass done"
+F=$(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1)
+W=$(find $OUT/pmc_write -name "*counter_collection.csv" | head -1)
+BATCH=$(python3 -c "import json;print(json.load(open('$OUT/bench.json'))['config']['scenes_per_gpu'])")
+python3 profiles/summarize.py pmc $F $W $BATCH $OUT/pmc_traffic.json
+cp $F $OUT/pmc_fetch_size.csv; cp $W $OUT/pmc_write_size.csv
+rm -rf $OUT/stats_default $OUT/stats_alone $OUT/pmc_fetch $OUT/pmc_write

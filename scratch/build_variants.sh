@@ -1,0 +1,11 @@
+# builds variants of libepnet_hip.so with different -D flags into scratch/libs/
+set -e
+cd /root/repo/epnet_amd/csrc
+mkdir -p ../../scratch/libs
+F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -I../../include"
+i=0
+while [ $# -gt 0 ]; do
+  name=$1; flags=$2; shift 2
+  /opt/rocm/bin/hipcc $F $flags -c fps.hip -o /tmp/fps_$name.o
+  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../scratch/libs/lib_$name.so /tmp/fps_$name.o ../lib/obj/ball_query.o ../lib/obj/group.o ../lib/obj/interpolate.o ../lib/obj/iou3d.o ../lib/obj/roipool3d.o ../lib/obj/host.o
+done
