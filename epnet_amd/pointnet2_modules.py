@@ -38,14 +38,16 @@ class _PointnetSAModuleBase(nn.Module):
         idx (B,npoint) int32 FPS indices or None). The 3-tuple (reference :72) is what
         lib/net/pointnet2_msg.py:214-218 unpacks; LI-Fusion consumes idx."""
         idx = None
+        # one spatial sort of the level's points serves the sampling and every ball query of the level
+        index = pointnet2_utils.scene_index(xyz) if self.npoint is not None and xyz.is_cuda else None
         if new_xyz is None and self.npoint is not None:
-            idx = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
+            idx = pointnet2_utils.furthest_point_sample(xyz, self.npoint, index)
             channels_first = xyz.transpose(1, 2).contiguous()
             new_xyz = pointnet2_utils.gather_operation(channels_first, idx).transpose(1, 2).contiguous()
 
         pooled = []
         for grouper, mlp in zip(self.groupers, self.mlps):
-            grouped = grouper(xyz, new_xyz, features)          # (B, 3+C, npoint, nsample)
+            grouped = grouper(xyz, new_xyz, features, index) if index is not None else grouper(xyz, new_xyz, features)
             pooled.append(self._pool(mlp(grouped)).squeeze(-1))  # (B, mlp[-1], npoint)
         return new_xyz, torch.cat(pooled, dim=1), idx
 

@@ -27,21 +27,32 @@ class FurthestPointSampling(Function):
     reference: pointnet2_utils.py:10-33"""
 
     @staticmethod
-    def forward(ctx, xyz: torch.Tensor, npoint: int) -> torch.Tensor:
+    def forward(ctx, xyz: torch.Tensor, npoint: int, index: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """index: optional scene_index(xyz) shared with the ball queries of the level (same result either way)"""
         assert xyz.is_contiguous()
         batch, n = xyz.shape[0], xyz.shape[1]
         out = _new(xyz, (batch, npoint), torch.int32)
         running_min = torch.full((batch, n), 1e10, dtype=torch.float32, device=xyz.device)
-        _ext.furthest_point_sampling_wrapper(batch, n, npoint, xyz, running_min, out)
+        if index is None:
+            _ext.furthest_point_sampling_wrapper(batch, n, npoint, xyz, running_min, out)
+        else:
+            _ext.furthest_point_sampling_indexed_wrapper(batch, n, npoint, xyz, index, running_min, out)
         ctx.mark_non_differentiable(out)
         return out
 
     @staticmethod
     def backward(ctx, grad=None):
-        return None, None
+        return None, None, None
 
 
 furthest_point_sample = FurthestPointSampling.apply
+
+
+def scene_index(xyz: torch.Tensor) -> Optional[torch.Tensor]:
+    """one spatial sort of the (B,N,3) points of an SA level for furthest_point_sample / ball_query /
+    QueryAndGroup (their optional trailing argument); None where the library indexes nothing. Beyond the
+    reference: its kernels scan all N points each."""
+    return _ext.scene_index(xyz.detach().contiguous())
 
 
 class GatherOperation(Function):
@@ -151,18 +162,22 @@ class BallQuery(Function):
     empty ball. reference: pointnet2_utils.py:200-225"""
 
     @staticmethod
-    def forward(ctx, radius: float, nsample: int, xyz: torch.Tensor, new_xyz: torch.Tensor) -> torch.Tensor:
+    def forward(ctx, radius: float, nsample: int, xyz: torch.Tensor, new_xyz: torch.Tensor,
+                index: Optional[torch.Tensor] = None) -> torch.Tensor:
         assert new_xyz.is_contiguous() and xyz.is_contiguous()
         batch, n = xyz.shape[0], xyz.shape[1]
         npoint = new_xyz.shape[1]
         idx = _new(xyz, (batch, npoint, nsample), torch.int32, zero=True)
-        _ext.ball_query_wrapper(batch, n, npoint, radius, nsample, new_xyz, xyz, idx)
+        if index is None:
+            _ext.ball_query_wrapper(batch, n, npoint, radius, nsample, new_xyz, xyz, idx)
+        else:
+            _ext.ball_query_indexed_wrapper(batch, n, npoint, radius, nsample, new_xyz, xyz, index, idx)
         ctx.mark_non_differentiable(idx)
         return idx
 
     @staticmethod
     def backward(ctx, a=None):
-        return None, None, None, None
+        return None, None, None, None, None
 
 
 ball_query = BallQuery.apply
@@ -203,8 +218,9 @@ class QueryAndGroup(nn.Module):
         super().__init__()
         self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
 
-    def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: Optional[torch.Tensor] = None):
-        idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
+    def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: Optional[torch.Tensor] = None,
+                index: Optional[torch.Tensor] = None):
+        idx = ball_query(self.radius, self.nsample, xyz, new_xyz, index)
         if features is None:
             assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
         coords_need_grad = torch.is_grad_enabled() and (xyz.requires_grad or new_xyz.requires_grad)
