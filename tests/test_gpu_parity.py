@@ -363,6 +363,53 @@ def test_three_interpolate_and_grad(oracle, b, c, m, n):
     np.testing.assert_allclose(host(grad), oracle.three_interpolate_grad(go, idx, w, m), rtol=1e-5, atol=1e-5)
 
 
+def test_scratch_free_entry_points_through_the_c_abi(oracle):
+    """the wrappers hand scratch to the *_ws / *_indexed entry points whenever the library accepts it; the plain
+    entry points (LDS-atomic gradients, self-sorting FPS, direct three_nn) must stay correct for callers without"""
+    from epnet_amd import _lib
+    l = _lib.lib()
+    s = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(41)
+    b, c, n, m, ns = 2, 24, 2048, 256, 16
+    go = rng.standard_normal((b, c, m, ns)).astype(np.float32)
+    idx = rng.integers(0, n, size=(b, m, ns)).astype(np.int32)
+    d_go, d_idx = dev(go), dev(idx)
+    grad = torch.zeros((b, c, n), device=DEV)
+    _lib.check(l.epnet_group_points_grad(b, c, n, m, ns, d_go.data_ptr(), d_idx.data_ptr(), grad.data_ptr(), s), "group_points_grad")
+    np.testing.assert_allclose(host(grad), oracle.group_points_grad(go, idx, n), rtol=1e-5, atol=1e-5)
+    # fused-tensor gradient: the feature channels sit behind 3 xyz channels
+    go3 = rng.standard_normal((b, 3 + c, m, ns)).astype(np.float32)
+    d_go3 = dev(go3)
+    grad = torch.zeros((b, c, n), device=DEV)
+    _lib.check(l.epnet_group_concat_grad(b, c, n, m, ns, d_go3.data_ptr(), d_idx.data_ptr(), grad.data_ptr(), 1, s), "group_concat_grad")
+    np.testing.assert_allclose(host(grad), oracle.group_points_grad(np.ascontiguousarray(go3[:, 3:]), idx, n), rtol=1e-5, atol=1e-5)
+
+    nn = 4096
+    gi = rng.standard_normal((b, c, nn)).astype(np.float32)
+    i3 = rng.integers(0, n, size=(b, nn, 3)).astype(np.int32)
+    w = rng.random((b, nn, 3)).astype(np.float32)
+    d_gi, d_i3, d_w = dev(gi), dev(i3), dev(w)
+    grad = torch.zeros((b, c, n), device=DEV)
+    _lib.check(l.epnet_three_interpolate_grad(b, c, nn, n, d_gi.data_ptr(), d_i3.data_ptr(), d_w.data_ptr(), grad.data_ptr(), s),
+               "three_interpolate_grad")
+    np.testing.assert_allclose(host(grad), oracle.three_interpolate_grad(gi, i3, w, n), rtol=1e-5, atol=1e-5)
+
+    unknown, known = rand_cloud(b, nn, seed=1, kind="kitti"), rand_cloud(b, n, seed=2, kind="kitti")
+    d_u, d_k = dev(unknown), dev(known)
+    d2 = torch.empty((b, nn, 3), device=DEV)
+    i = torch.empty((b, nn, 3), dtype=torch.int32, device=DEV)
+    _lib.check(l.epnet_three_nn(b, nn, n, d_u.data_ptr(), d_k.data_ptr(), d2.data_ptr(), i.data_ptr(), s), "three_nn")
+    o_d2, o_i = oracle.three_nn(unknown, known)
+    np.testing.assert_array_equal(host(i), o_i)
+    np.testing.assert_array_equal(host(d2), o_d2)
+
+    centres = np.ascontiguousarray(known[:, ::8])
+    d_c = dev(centres)
+    out = torch.full((b, centres.shape[1], 24), -3, dtype=torch.int32, device=DEV)
+    _lib.check(l.epnet_ball_query(b, n, centres.shape[1], 0.7, 24, d_c.data_ptr(), d_k.data_ptr(), out.data_ptr(), s), "ball_query")
+    np.testing.assert_array_equal(host(out), oracle.ball_query(0.7, 24, known, centres))
+
+
 # ------------------------------------------------------------------------------------------------ iou3d
 
 def boxes_bev(num, seed):
