@@ -603,6 +603,166 @@ __global__ __launch_bounds__(64 * kW) void fps_indexed_kernel(int n, int m, cons
     }
 }
 
+// ---- scenes beyond the register file (16384 < N <= 65536), over a scene index ------------------------
+// The points stay in the index (L2-resident, <= 1 MB) and the running distances in the caller's temp buffer;
+// only the bucket summaries live in registers: thread q owns bucket q (64 consecutive sorted points) -- its
+// box (from the index), its maximum running distance bm and the rank and coordinates of the point holding it.
+// A round tests all buckets against the new sample with the same exact lower bound, re-reads and updates only
+// the active buckets (one wave per bucket, a coalesced 1 KB row of the index), and finds the arg-max over the
+// summaries exactly as fps_rounds does (wave maximum, 64-bit LDS atomic key, one barrier).
+// rank(k) = (bitreverse10(k mod 1024) << 6) | (k div 1024) -- 16 bits for k < 65536.
+__device__ __forceinline__ unsigned rank16(int k) { return (bitrev_lg((unsigned)k & 1023u, 10) << 6) | ((unsigned)k >> 10); }
+__device__ __forceinline__ int unrank16(unsigned r) { return (int)(bitrev_lg(r >> 6, 10) + ((r & 63u) << 10)); }
+
+constexpr int kBigThreads = 1024;
+#ifdef EPNET_BIG_DEBUG
+__device__ int g_dbg[4096];
+#endif
+
+__global__ __launch_bounds__(kBigThreads) void fps_bigscene_kernel(int n, int np, int m, const float *__restrict__ xyz,
+                                                                  const float4 *__restrict__ sorted,
+                                                                  const float *__restrict__ boxes,
+                                                                  float *__restrict__ temp, int *__restrict__ idxs) {
+    __shared__ unsigned long long s_key[3];
+    __shared__ float4 s_rec[2][16];
+    __shared__ int s_idx[kIdxBufP];
+    const int q = threadIdx.x;
+    const int lane = q & 63, wave = q >> 6;
+    const int nb = np >> 6;
+    xyz += (size_t)blockIdx.x * n * 3;
+    sorted += (size_t)blockIdx.x * np;
+    boxes += (size_t)blockIdx.x * nb * 6;
+    temp += (size_t)blockIdx.x * n;
+    idxs += (size_t)blockIdx.x * m;
+    const int kNeg1 = __float_as_int(-1.f);
+
+    const bool own = q < nb;
+    float lox = 0.f, hix = 0.f, loy = 0.f, hiy = 0.f, loz = 0.f, hiz = 0.f;
+    if (own) {
+        const float *bx = boxes + q * 6;
+        lox = bx[0]; hix = bx[1]; loy = bx[2]; hiy = bx[3]; loz = bx[4]; hiz = bx[5];
+    }
+    int bm = kNeg1;             // maximum running distance of my bucket (bits); -1: nothing real in it
+    unsigned brank = 0xFFFFu;   // reference rank of the point holding it
+    float bxx = 0.f, byy = 0.f, bzz = 0.f;
+
+    // (re)computes the summary of bucket bb of this wave; with `update`, first lowers its distances by the sample c
+    auto refresh = [&](int bb, bool update, float cx, float cy, float cz) {
+        const float4 p = sorted[(bb << 6) + lane];
+        const int k = __float_as_int(p.w);
+        int t = kNeg1;
+        if (k >= 0) {
+            t = __float_as_int(temp[k]);
+            if (update) {
+                const float dx = p.x - cx, dy = p.y - cy, dz = p.z - cz;
+                const float d = dx * dx + dy * dy + dz * dz;
+                const int tn = min(__float_as_int(d), t);  // == fminf(d, temp[k])
+                if (tn != t) temp[k] = __int_as_float(tn);
+                t = tn;
+            }
+        }
+        const int mx = wave_max_all(t);
+        const unsigned r = (t == mx && k >= 0) ? rank16(k) : 0xFFFFFFFFu;
+        unsigned long long holders = __ballot(r != 0xFFFFFFFFu);
+        unsigned rwin = 0xFFFFu;
+        int wl = 0;
+        if (holders) {
+            if (holders & (holders - 1ull)) holders = __ballot(r == wave_min_all(r));  // several: the smallest rank
+            wl = (int)__builtin_ctzll(holders);
+            rwin = (unsigned)__builtin_amdgcn_readlane((int)r, wl);
+        }
+        const float wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.x), wl));
+        const float wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.y), wl));
+        const float wz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.z), wl));
+        if (lane == (bb & 63)) {
+            bm = mx;
+            brank = rwin;
+            bxx = wx; byy = wy; bzz = wz;
+        }
+    };
+
+    for (int j = 0; j < 64; ++j) {
+        const int bb = (wave << 6) + j;
+        if (bb < nb) refresh(bb, false, 0.f, 0.f, 0.f);  // wave-uniform
+    }
+    if (q < 3) s_key[q] = 0ull;
+    if (q == 0) s_idx[0] = 0;  // rank 0 == point 0
+    float cx = xyz[0], cy = xyz[1], cz = xyz[2];
+    __syncthreads();
+
+    __builtin_amdgcn_s_setprio(3);
+    bool stale = true;
+    int wbest = kNeg1;
+    bool publisher = false;
+    int kb = 1;
+    for (int it = 1; it < m; ++it) {
+        // A. which buckets can change?  (same fp32 expression as the point distance: exact)
+        const float px = __builtin_amdgcn_fmed3f(cx, lox, hix), py = __builtin_amdgcn_fmed3f(cy, loy, hiy),
+                    pz = __builtin_amdgcn_fmed3f(cz, loz, hiz);
+        const float bdx = px - cx, bdy = py - cy, bdz = pz - cz;
+        const float L = bdx * bdx + bdy * bdy + bdz * bdz;
+        unsigned long long active = __ballot(own && __float_as_int(L) < bm);
+        stale = stale || active != 0ull;
+        // B. re-read and update them
+        while (active) {
+            const int j = (int)__builtin_ctzll(active);
+            active &= active - 1ull;
+            refresh((wave << 6) + j, true, cx, cy, cz);
+        }
+        // C. this wave's best bucket (ties by rank)
+#ifdef EPNET_BIG_NOCACHE
+        stale = true;
+#endif
+        if (stale) {
+            stale = false;
+            wbest = wave_max_all(bm);
+            unsigned long long cand = __ballot(bm == wbest && bm != kNeg1);
+            if (cand & (cand - 1ull)) {
+                // (the cross-lane minimum must not sit behind a short-circuit '&&': it needs every lane)
+                const unsigned rmin = wave_min_all(bm == wbest ? brank : 0xFFFFFFFFu);
+                cand = __ballot(bm == wbest && brank == rmin);
+            }
+            publisher = cand != 0ull && lane == (int)__builtin_ctzll(cand);
+        }
+        const int buf = it & 1;
+        if (publisher) {
+            s_rec[buf][wave] = make_float4(bxx, byy, bzz, 0.f);
+            const unsigned long long key =
+                ((unsigned long long)(unsigned)wbest << 32) | (unsigned long long)(((0xFFFFu - brank) << 4) | (unsigned)wave);
+            __hip_atomic_fetch_max(&s_key[kb], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __syncthreads();
+        // D. the winner
+        const unsigned klo = (unsigned)s_key[kb];
+        const float4 rec = s_rec[buf][klo & 15u];
+        cx = rec.x;
+        cy = rec.y;
+        cz = rec.z;
+        const int kb2 = kb == 0 ? 2 : kb - 1;
+        kb = kb == 2 ? 0 : kb + 1;
+        if (wave == 0) {
+            s_idx[it & (kIdxBufP - 1)] = (int)(0xFFFFu - (klo >> 4));
+            if (lane == 0) s_key[kb2] = 0ull;
+            if ((it & (kIdxBufP - 1)) == kIdxBufP - 1) {
+                const int base = it - (kIdxBufP - 1);
+                for (int e = lane; e < kIdxBufP; e += 64) idxs[base + e] = unrank16((unsigned)s_idx[e]);
+            }
+        }
+    }
+    if (wave == 0) {
+        const int base = (m - 1) & ~(kIdxBufP - 1);
+        for (int e = lane; base + e < m; e += 64) idxs[base + e] = unrank16((unsigned)s_idx[e]);
+    }
+#ifdef EPNET_BIG_DEBUG
+    if (blockIdx.x == 0) {
+        g_dbg[q] = bm;
+        g_dbg[1024 + q] = (int)brank;
+        g_dbg[2048 + q] = publisher ? 1 : 0;
+        g_dbg[3072 + q] = wbest;
+    }
+#endif
+}
+
 }  // namespace pruned
 
 // ---- generic paths (tiny clouds with a reference block < one wave; clouds beyond the register file)
@@ -775,13 +935,20 @@ extern "C" int epnet_furthest_point_sampling_indexed(int b, int n, int m, const 
                                                      epnet_stream_t stream) {
     const size_t need = scene_index_bytes(b, n);
     // n <= 1024: the reference block size (hence the tie-break rank) depends on n; the one-wave kernel handles it
-    if (need == 0 || !index || n <= 1024 || n > 16384 || m <= 1)
+    if (need == 0 || !index || n <= 1024 || m <= 1 || (n > 16384 && !temp))
         return epnet_furthest_point_sampling(b, n, m, xyz, temp, idx, stream);
     EPNET_REQUIRE(idx);
     if (index_bytes < need) return EPNET_ENOMEM;
     hipStream_t s = (hipStream_t)stream;
     const float4 *sorted = (const float4 *)index;
     dim3 grid(b);
+    if (n > 16384) {  // beyond the register file: bucket summaries in registers, points re-read from the index
+        EPNET_REQUIRE(xyz);
+        const int np = scene_index_np(n);
+        hipLaunchKernelGGL(pruned::fps_bigscene_kernel, grid, dim3(pruned::kBigThreads), 0, s, n, np, m, xyz, sorted,
+                           (const float *)(sorted + (size_t)b * np), temp, idx);
+        return check_launch("furthest_point_sampling");
+    }
     static const int wide = getenv("EPNET_FPS_WIDE") ? atoi(getenv("EPNET_FPS_WIDE")) : 0;
 #define EPNET_FPS_INDEXED(W_, P_) \
     hipLaunchKernelGGL((pruned::fps_indexed_kernel<W_, P_>), grid, dim3(64 * W_), 0, s, n, m, sorted, temp, idx)

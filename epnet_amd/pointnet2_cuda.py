@@ -77,8 +77,16 @@ def furthest_point_sampling_wrapper(b, n, m, points, temp, idx):
     """furthest_point_sampling_wrapper, sampling.cpp:36-46"""
     pp, pt, pi = dev_ptr(points, "points", _F), dev_ptr(temp, "temp", _F), dev_ptr(idx, "idx", _I)
     need(points, b * n * 3, "points"); need(temp, b * n, "temp"); need(idx, b * m, "idx")
+    l = _lib.lib()
     with on_device_of(points) as s:
-        _lib.check(_lib.lib().epnet_furthest_point_sampling(b, n, m, pp, pt, pi, s), "furthest_point_sampling")
+        if 16384 < n <= 65536:  # scenes beyond the register file: the kernel works over a scene index (scratch)
+            nbytes = l.epnet_scene_index_bytes(b, n)
+            index = torch.empty((nbytes,), dtype=torch.uint8, device=points.device)
+            _lib.check(l.epnet_scene_index_build(b, n, pp, index.data_ptr(), nbytes, s), "scene_index_build")
+            _lib.check(l.epnet_furthest_point_sampling_indexed(b, n, m, pp, index.data_ptr(), nbytes, pt, pi, s),
+                       "furthest_point_sampling")
+        else:
+            _lib.check(l.epnet_furthest_point_sampling(b, n, m, pp, pt, pi, s), "furthest_point_sampling")
     return 1
 
 

@@ -72,9 +72,10 @@ def test_fps_ties_all_equal_and_heavy_duplicates(oracle):
 
 
 def test_fps_running_distance_buffer_and_streaming_path(oracle):
-    """temp is an in/out buffer of the extension (sampling.cpp:36-46); n > 16384 takes the streaming kernel"""
+    """temp is an in/out buffer of the extension (sampling.cpp:36-46); 16384 < n <= 65536 takes the big-scene
+    kernel over a private index, n > 65536 the streaming kernel"""
     from epnet_amd import pointnet2_cuda as ext
-    for n, m in ((4096, 200), (20000, 48)):
+    for n, m in ((4096, 200), (20000, 48), (70000, 24)):
         xyz = rand_cloud(2, n, seed=7, kind="kitti")
         temp = torch.full((2, n), 1e10, device=DEV)
         idx = torch.empty((2, m), dtype=torch.int32, device=DEV)
@@ -115,7 +116,8 @@ def test_fps_full_size_properties():
     (2, 2048, 512, "ubox"), (2, 1025, 64, "kitti"), (2, 1500, 1499, "dup"), (2, 10000, 33, "ubox"),
     (2, 1024, 256, "kitti"),     # indexed for the ball queries only: sampling takes the one-wave kernel
     (2, 900, 100, "kitti"),      # below the indexed range: index is None, plain path
-    (1, 20000, 20, "kitti"),     # index exists (ball query uses it) but sampling falls back above 16384
+    (1, 20000, 20, "kitti"),     # beyond the register file: bucket summaries in registers, points in the index
+    (2, 30000, 700, "dup"), (1, 65536, 1500, "kitti"), (2, 16385, 300, "ubox"),
 ])
 def test_fps_over_scene_index_matches_oracle(oracle, b, n, m, kind):
     """epnet_furthest_point_sampling_indexed: same indices AND running distances as the plain entry point"""
