@@ -95,6 +95,29 @@ def main():
         gp = torch.zeros((bsz, 96, 4096), device=dev)
         ms = timeit(lambda: p2.group_points_grad_wrapper(bsz, 96, 4096, 1024, 32, go, idx, gp))
         report("group_points_grad", {"B": bsz, "C": 96, "N": 4096, "M": 1024, "ns": 32}, ms, bsz * (96 * 1024 * 32 * 4 + 1024 * 32 * 4 + 96 * 4096 * 4))
+    # ---- BASELINE config 5: dense 65536-point scenes, one SA level with nsample = 64 (ball-query stress)
+    for bsz in (1, 16):
+        n, m, ns, c, radius = 65536, 16384, 64, 32, 0.4
+        xyz = synth.scenes("kitti", bsz, n, seed=9).to(dev)
+        index = torch.empty((p2.scene_index_bytes(bsz, n),), dtype=torch.uint8, device=dev)
+        ms = timeit(lambda: p2.scene_index_build_wrapper(bsz, n, xyz, index))
+        report("scene_index_build", {"B": bsz, "N": n}, ms, bsz * (n * 12 + n * 16), "this implementation's own structure")
+        temp = torch.empty((bsz, n), device=dev); fidx = torch.empty((bsz, m), dtype=i32, device=dev)
+
+        def fps():
+            temp.fill_(1e10)
+            p2.furthest_point_sampling_indexed_wrapper(bsz, n, m, xyz, index, temp, fidx)
+        ms = timeit(fps) if bsz == 1 else timeit(fps)
+        report("furthest_point_sampling", {"B": bsz, "N": n, "M": m}, ms, bsz * (n * 12 + m * 4), "big-scene kernel over the index")
+        new_xyz = torch.gather(xyz, 1, fidx.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+        bq = torch.empty((bsz, m, ns), dtype=i32, device=dev)
+        ms = timeit(lambda: p2.ball_query_indexed_wrapper(bsz, n, m, radius, ns, new_xyz, xyz, index, bq))
+        report("ball_query", {"B": bsz, "N": n, "M": m, "r": radius, "ns": ns}, ms, bsz * (n * 12 + m * 12 + m * ns * 4))
+        feats = torch.randn((bsz, c, n), generator=g).to(dev)
+        grouped = torch.empty((bsz, 3 + c, m, ns), device=dev)
+        ms = timeit(lambda: p2.group_concat_wrapper(bsz, c, n, m, ns, xyz, new_xyz, feats, bq, grouped, True))
+        report("group_concat", {"B": bsz, "C": c, "N": n, "M": m, "ns": ns}, ms,
+               bsz * (2 * m * ns * 4 + 3 * n * 4 + c * n * 4 + (3 + c) * m * ns * 4))
 
 
 if __name__ == "__main__":

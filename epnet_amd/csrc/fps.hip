@@ -646,12 +646,28 @@ __global__ __launch_bounds__(kBigThreads) void fps_bigscene_kernel(int n, int np
     unsigned brank = 0xFFFFu;   // reference rank of the point holding it
     float bxx = 0.f, byy = 0.f, bzz = 0.f;
 
+    // original indices of this wave's 64 x 64 points, two per register: with them at hand a bucket's coordinates
+    // and its running distances are fetched side by side instead of one L2 round trip after the other
+    // (positions >= n are padding: the sort puts them last)
+    typedef int veck __attribute__((ext_vector_type(32)));
+    veck kk;
+#pragma unroll
+    for (int j = 0; j < 64; j += 2) {
+        const int p0 = (((wave << 6) + j) << 6) + lane, p1 = p0 + 64;
+        const unsigned k0 = p0 < n ? (unsigned)__float_as_int(sorted[p0].w) : 0xFFFFu;
+        const unsigned k1 = p1 < n ? (unsigned)__float_as_int(sorted[p1].w) : 0xFFFFu;
+        kk[j >> 1] = (int)(k0 | (k1 << 16));
+    }
+
     // (re)computes the summary of bucket bb of this wave; with `update`, first lowers its distances by the sample c
     auto refresh = [&](int bb, bool update, float cx, float cy, float cz) {
-        const float4 p = sorted[(bb << 6) + lane];
-        const int k = __float_as_int(p.w);
+        const int j = bb & 63;
+        const int pos = (bb << 6) + lane;
+        const int k = (int)(((unsigned)kk[j >> 1] >> ((j & 1) << 4)) & 0xFFFFu);
+        const bool real = pos < n;
+        const float4 p = sorted[pos];
         int t = kNeg1;
-        if (k >= 0) {
+        if (real) {
             t = __float_as_int(temp[k]);
             if (update) {
                 const float dx = p.x - cx, dy = p.y - cy, dz = p.z - cz;
@@ -662,7 +678,7 @@ __global__ __launch_bounds__(kBigThreads) void fps_bigscene_kernel(int n, int np
             }
         }
         const int mx = wave_max_all(t);
-        const unsigned r = (t == mx && k >= 0) ? rank16(k) : 0xFFFFFFFFu;
+        const unsigned r = (t == mx && real) ? rank16(k) : 0xFFFFFFFFu;
         unsigned long long holders = __ballot(r != 0xFFFFFFFFu);
         unsigned rwin = 0xFFFFu;
         int wl = 0;
@@ -674,7 +690,7 @@ __global__ __launch_bounds__(kBigThreads) void fps_bigscene_kernel(int n, int np
         const float wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.x), wl));
         const float wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.y), wl));
         const float wz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.z), wl));
-        if (lane == (bb & 63)) {
+        if (lane == j) {
             bm = mx;
             brank = rwin;
             bxx = wx; byy = wy; bzz = wz;
