@@ -79,7 +79,11 @@ def main():
         known = unknown[:, :m].contiguous()
         d2 = torch.empty((bsz, n, 3), device=dev); idx = torch.empty((bsz, n, 3), dtype=i32, device=dev)
         ms = timeit(lambda: p2.three_nn_wrapper(bsz, n, m, unknown, known, d2, idx))
-        report("three_nn", {"B": bsz, "n": n, "m": m}, ms, bsz * (n * 12 + m * 12 + n * 24))
+        report("three_nn", {"B": bsz, "n": n, "m": m}, ms, bsz * (n * 12 + m * 12 + n * 24), "builds its own index of the known set")
+        ui, ki = p2.scene_index(unknown), p2.scene_index(known)
+        if ki is not None:
+            ms = timeit(lambda: p2.three_nn_indexed_wrapper(bsz, n, m, unknown, known, ui, ki, d2, idx))
+            report("three_nn", {"B": bsz, "n": n, "m": m}, ms, bsz * (n * 12 + m * 12 + n * 24), "over the scene indices of both point sets")
         feats = torch.randn((bsz, c, m), generator=g).to(dev)
         w = torch.rand((bsz, n, 3), generator=g).to(dev); w = (w / w.sum(-1, keepdim=True)).contiguous()
         out = torch.empty((bsz, c, n), device=dev)

@@ -116,7 +116,6 @@ __global__ __launch_bounds__(kBqThreads) void ball_query_kernel(int n, int m, fl
 // The point test is the same expression as above: d2 = (cx-x)*(cx-x) + (cy-y)*(cy-y) + (cz-z)*(cz-z).
 
 constexpr int kIxThreads = 1024;
-constexpr int kIxMaxPoints = 65536;
 
 __global__ __launch_bounds__(kIxThreads) void bq_index_kernel(int n, int np, const float *__restrict__ xyz,
                                                               float4 *__restrict__ sorted, float *__restrict__ boxes,

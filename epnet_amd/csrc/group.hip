@@ -315,7 +315,7 @@ __global__ __launch_bounds__(kCsrThreads) void scatter_rows_csr_kernel(int c, in
     }
 }
 
-int epnet::csr_build_launch(int b, int n, int p, const int *idx, int *offsets, int *perm, hipStream_t s) {
+int csr_build_launch(int b, int n, int p, const int *idx, int *offsets, int *perm, hipStream_t s) {
     const int per = (n + kCsrThreads - 1) / kCsrThreads;
     hipLaunchKernelGGL(csr_build_kernel, dim3(b), dim3(kCsrThreads), (size_t)kCsrThreads * (per + 1) * sizeof(int), s, n, p, idx,
                        offsets, perm);

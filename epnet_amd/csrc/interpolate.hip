@@ -227,6 +227,144 @@ __global__ __launch_bounds__(kNnIxThreads) void three_nn_indexed_kernel(int n, i
     }
 }
 
+// ---- three_nn with BOTH point sets indexed -----------------------------------------------------------
+// One wave per BUCKET of 64 spatially adjacent unknown points (one unknown per lane, taken from the unknown set's
+// own scene index), so the lanes of a wave want almost the same known points:
+//   1. the known buckets are visited in order of increasing box-to-box gap to the unknown bucket (the nearest one
+//      gives every lane three candidates and with them an upper bound d3 on its third-nearest distance);
+//   2. for a known bucket K each lane evaluates the lower bound L = |clamp(u, box_K) - u|^2 (same fp32
+//      expression as the distance); K is scanned -- by the whole wave -- if ANY lane has L <= its d3; the walk
+//      stops when the smallest remaining gap (a lower bound of every lane's L) exceeds every lane's d3.
+// A scan walks the bucket's 64 known points as wave-uniform (scalar) loads; every lane keeps its own three best
+// under the lexicographic (d, k) order, so there is no cross-lane merge at all. A bucket that is not scanned has
+// L > d3 for every lane: it holds neither a closer point nor an equal one with a smaller index -- the result is
+// the reference's, bit for bit. ~2x fewer instructions per unknown than the wave-per-unknown kernel above.
+constexpr int kNnTileThreads = 256;
+
+constexpr int kNnTileMaxBoxes = 1024;  // known-bucket boxes staged in LDS (24 KB): m <= 65536
+
+__global__ __launch_bounds__(kNnTileThreads) void three_nn_tile_kernel(int n, int npu, int npk,
+                                                                       const float4 *__restrict__ sorted_u,
+                                                                       const float *__restrict__ boxes_u,
+                                                                       const float4 *__restrict__ sorted_k,
+                                                                       const float *__restrict__ boxes_k,
+                                                                       float *__restrict__ dist2, int *__restrict__ idx) {
+    extern __shared__ float s_boxes[];                  // the known buckets' boxes, shared by the 4 waves
+    __shared__ float4 s_pts[kNnTileThreads / 64][64];   // the known bucket a wave is scanning
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bs = blockIdx.y;
+    const int ub = blockIdx.x * (kNnTileThreads / 64) + wave;
+    sorted_u += (size_t)bs * npu;
+    boxes_u += (size_t)bs * (npu >> 6) * 6;
+    sorted_k += (size_t)bs * npk;
+    boxes_k += (size_t)bs * (npk >> 6) * 6;
+    const int nbk = npk >> 6;
+    for (int e = threadIdx.x; e < nbk * 6; e += kNnTileThreads) s_boxes[e] = boxes_k[e];
+    __syncthreads();
+    if (ub >= (npu >> 6)) return;  // wave-uniform; no block-level barrier below
+    const float4 u = sorted_u[(ub << 6) + lane];
+    const int ku = __float_as_int(u.w);
+    const bool valid = ku >= 0;
+    if (!__ballot(valid)) return;  // a bucket of padding
+    constexpr unsigned kNone = 0xFFFFFFFFu;
+    float4 *pts = s_pts[wave];
+
+    unsigned d0 = kNone, d1 = kNone, d2 = kNone;
+    int i0 = 0x7fffffff, i1 = 0x7fffffff, i2 = 0x7fffffff;
+    auto offer = [&](const float4 p) {
+        const int k = __float_as_int(p.w);
+        const float dx = u.x - p.x, dy = u.y - p.y, dz = u.z - p.z;
+        const float d = dx * dx + dy * dy + dz * dz;
+        // padding rows and non-finite distances never enter a list, as in the reference (interpolate_gpu.cu:37-48)
+        const unsigned db = (k >= 0 && d < __builtin_huge_valf()) ? __float_as_uint(d) : kNone;
+        const bool lt2 = db < d2 || (db == d2 && k < i2);
+        if (!__ballot(lt2 && db != kNone)) return;  // nobody's list changes
+        const bool lt0 = db < d0 || (db == d0 && k < i0), lt1 = db < d1 || (db == d1 && k < i1);
+        if (db != kNone) {
+            d2 = lt1 ? d1 : (lt2 ? db : d2);  i2 = lt1 ? i1 : (lt2 ? k : i2);
+            d1 = lt0 ? d0 : (lt1 ? db : d1);  i1 = lt0 ? i0 : (lt1 ? k : i1);
+            d0 = lt0 ? db : d0;               i0 = lt0 ? k : i0;
+        }
+    };
+    auto scan = [&](int kb) {
+        __builtin_amdgcn_wave_barrier();
+        pts[lane] = sorted_k[((size_t)kb << 6) + lane];  // one coalesced row, then broadcast reads out of LDS
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+        for (int j = 0; j < 64; j += 4) {
+            const float4 p0 = pts[j], p1 = pts[j + 1], p2 = pts[j + 2], p3 = pts[j + 3];
+            offer(p0);
+            offer(p1);
+            offer(p2);
+            offer(p3);
+        }
+    };
+
+    // box-to-box gap between this unknown bucket and known bucket kb: a lower bound of every lane's L (each term
+    // |u - clamp(u)| >= the gap of its axis, and fp32 sub / mul / add are monotone), kNone for a bucket of padding
+    const float *ubx = boxes_u + ub * 6;
+    const float ulx = ubx[0], uhx = ubx[1], uly = ubx[2], uhy = ubx[3], ulz = ubx[4], uhz = ubx[5];
+    auto gap_of = [&](int kb) -> unsigned {
+        if (kb >= nbk) return kNone;
+        const float *bx = s_boxes + kb * 6;
+        const float gx = fmaxf(0.f, fmaxf(bx[0] - uhx, ulx - bx[1])), gy = fmaxf(0.f, fmaxf(bx[2] - uhy, uly - bx[3])),
+                    gz = fmaxf(0.f, fmaxf(bx[4] - uhz, ulz - bx[5]));
+        const float g2 = gx * gx + gy * gy + gz * gz;
+        return (bx[0] < 3.0e38f && g2 < __builtin_huge_valf()) ? __float_as_uint(g2) : kNone;
+    };
+    // does any lane still need known bucket kb?  (d2 == kNone: its list is not full yet)
+    auto wanted = [&](int kb) -> bool {
+        const float *bx = s_boxes + kb * 6;  // wave-uniform: broadcast reads
+        const float px = __builtin_amdgcn_fmed3f(u.x, bx[0], bx[1]), py = __builtin_amdgcn_fmed3f(u.y, bx[2], bx[3]),
+                    pz = __builtin_amdgcn_fmed3f(u.z, bx[4], bx[5]);
+        const float dx = u.x - px, dy = u.y - py, dz = u.z - pz;
+        const float Lf = dx * dx + dy * dy + dz * dz;
+        const unsigned L = Lf < __builtin_huge_valf() ? __float_as_uint(Lf) : kNone;
+        return __ballot(valid && L != kNone && L <= d2) != 0ull;
+    };
+    if (nbk <= 64) {
+        // known buckets in order of increasing gap: the lists tighten early, and once the smallest remaining gap
+        // exceeds every lane's third distance no remaining bucket can matter
+        unsigned g = gap_of(lane);
+        for (;;) {
+            const unsigned mn = wave_min_all(g);
+            if (mn == kNone || !__ballot(valid && mn <= d2)) break;
+            const int kb = (int)__builtin_ctzll(__ballot(g == mn));
+            if (lane == kb) g = kNone;
+            if (wanted(kb)) scan(kb);
+        }
+    } else {
+        // many known buckets: seed with the nearest one, then all others in index order
+        unsigned best = kNone;
+        int seed = 0;
+        for (int k0 = 0; k0 < nbk; k0 += 64) {
+            const unsigned g = gap_of(k0 + lane);
+            const unsigned mn = wave_min_all(g);
+            if (mn < best) {
+                best = mn;
+                seed = k0 + (int)__builtin_ctzll(__ballot(g == mn));
+            }
+        }
+        seed = __builtin_amdgcn_readfirstlane(seed);
+        if (best != kNone) scan(seed);
+        for (int kb = 0; kb < nbk; ++kb) {
+            if (kb == seed && best != kNone) continue;
+            if (wanted(kb)) scan(kb);
+        }
+    }
+    if (valid) {
+        float *dd = dist2 + ((size_t)bs * n + ku) * 3;
+        int *ii = idx + ((size_t)bs * n + ku) * 3;
+        // unfilled slot: (float)1e40 = inf, index 0 (interpolate_gpu.cu:30-31)
+        dd[0] = d0 != kNone ? __uint_as_float(d0) : __builtin_huge_valf();
+        dd[1] = d1 != kNone ? __uint_as_float(d1) : __builtin_huge_valf();
+        dd[2] = d2 != kNone ? __uint_as_float(d2) : __builtin_huge_valf();
+        ii[0] = d0 != kNone ? i0 : 0;
+        ii[1] = d1 != kNone ? i1 : 0;
+        ii[2] = d2 != kNone ? i2 : 0;
+    }
+}
+
 constexpr int kTiThreads = 256;
 constexpr int kTiChan = 16;
 
@@ -535,4 +673,37 @@ extern "C" int epnet_three_interpolate_grad_ws(int b, int c, int n, int m, const
         default: hipLaunchKernelGGL(three_interpolate_grad_csr_kernel<1>, grid, dim3(kTigThreads), lds, s, c, n, m, grad_out, weight, offsets, perm, grad_points); break;
     }
     return check_launch("three_interpolate_grad");
+}
+
+// three_nn over scene indices built beforehand (epnet_scene_index_build): of the known set, and optionally of the
+// unknown set as well. Same results as epnet_three_nn.
+extern "C" int epnet_three_nn_indexed(int b, int n, int m, const float *unknown, const float *known,
+                                      const void *unknown_index, size_t unknown_index_bytes, const void *known_index,
+                                      size_t known_index_bytes, float *dist2, int *idx, epnet_stream_t stream) {
+    const size_t need_k = scene_index_bytes(b, m);
+    if (need_k == 0 || !known_index) return epnet_three_nn(b, n, m, unknown, known, dist2, idx, stream);
+    EPNET_REQUIRE(b >= 0 && n >= 0);
+    if (b == 0 || n == 0) return EPNET_OK;
+    EPNET_REQUIRE(dist2 && idx);
+    if (known_index_bytes < need_k) return EPNET_ENOMEM;
+    EPNET_REQUIRE(b <= 65535);
+    hipStream_t s = (hipStream_t)stream;
+    const int npk = scene_index_np(m);
+    const float4 *sorted_k = (const float4 *)known_index;
+    const float *boxes_k = (const float *)(sorted_k + (size_t)b * npk);
+    const size_t need_u = scene_index_bytes(b, n);
+    if (need_u != 0 && unknown_index && (npk >> 6) <= kNnTileMaxBoxes) {
+        if (unknown_index_bytes < need_u) return EPNET_ENOMEM;
+        const int npu = scene_index_np(n);
+        const float4 *sorted_u = (const float4 *)unknown_index;
+        const float *boxes_u = (const float *)(sorted_u + (size_t)b * npu);
+        dim3 grid(div_up(npu >> 6, kNnTileThreads / 64), b);
+        hipLaunchKernelGGL(three_nn_tile_kernel, grid, dim3(kNnTileThreads), (size_t)(npk >> 6) * 6 * sizeof(float), s, n, npu,
+                           npk, sorted_u, boxes_u, sorted_k, boxes_k, dist2, idx);
+        return check_launch("three_nn");
+    }
+    EPNET_REQUIRE(unknown);
+    dim3 grid(div_up(n, kNnIxThreads / 64), b);
+    hipLaunchKernelGGL(three_nn_indexed_kernel, grid, dim3(kNnIxThreads), 0, s, n, m, npk, unknown, sorted_k, boxes_k, dist2, idx);
+    return check_launch("three_nn");
 }

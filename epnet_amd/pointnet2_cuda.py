@@ -182,6 +182,18 @@ def furthest_point_sampling_indexed_wrapper(b, n, m, points, index, temp, idx):
     return 1
 
 
+def three_nn_indexed_wrapper(b, n, m, unknown, known, unknown_index, known_index, dist2, idx):
+    """three_nn_wrapper over scene indices of `known` and (optionally) of `unknown` (same results)"""
+    pu, pk = dev_ptr(unknown, "unknown", _F), dev_ptr(known, "known", _F)
+    pd, pi = dev_ptr(dist2, "dist2", _F), dev_ptr(idx, "idx", _I)
+    need(unknown, b * n * 3, "unknown"); need(known, b * m * 3, "known"); need(dist2, b * n * 3, "dist2"); need(idx, b * n * 3, "idx")
+    pux, nu = _index_args(unknown_index, unknown)
+    pkx, nk = _index_args(known_index, known)
+    with on_device_of(unknown) as s:
+        _lib.check(_lib.lib().epnet_three_nn_indexed(b, n, m, pu, pk, pux, nu, pkx, nk, pd, pi, s), "three_nn")
+    return 1
+
+
 def ball_query_indexed_wrapper(b, n, m, radius, nsample, new_xyz, xyz, index, idx):
     """ball_query_wrapper over a scene index of `xyz` (same results)"""
     pn, pxyz, pi = dev_ptr(new_xyz, "new_xyz", _F), dev_ptr(xyz, "xyz", _F), dev_ptr(idx, "idx", _I)

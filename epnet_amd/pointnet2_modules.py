@@ -94,7 +94,10 @@ class PointnetFPModule(nn.Module):
         if known is None:
             spread = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
         else:
-            dist, idx = pointnet2_utils.three_nn(unknown, known)
+            # the SA modules of the two levels have indexed both point sets already (pointnet2_utils.scene_index)
+            known_index = pointnet2_utils.scene_index(known)
+            unknown_index = pointnet2_utils.scene_index(unknown) if known_index is not None else None
+            dist, idx = pointnet2_utils.three_nn(unknown, known, unknown_index, known_index)
             inv = 1.0 / (dist + 1e-8)                               # reference :157-159
             weight = inv / torch.sum(inv, dim=2, keepdim=True)
             spread = pointnet2_utils.three_interpolate(known_feats, idx, weight)

@@ -8,6 +8,7 @@ plumbing: outputs are allocated on the INPUT's device (the reference uses
 ``torch.cuda.FloatTensor(...)``, i.e. whatever device is current), and errors raise instead of
 killing the process.
 """
+import weakref
 from typing import Optional, Tuple
 
 import torch
@@ -48,11 +49,29 @@ class FurthestPointSampling(Function):
 furthest_point_sample = FurthestPointSampling.apply
 
 
-def scene_index(xyz: torch.Tensor) -> Optional[torch.Tensor]:
+_INDEX_CACHE = {}  # id(tensor) -> (weakref, tensor._version, index): the SA level's index is found again by its FP module
+
+
+def scene_index(xyz: torch.Tensor, cached_only: bool = False) -> Optional[torch.Tensor]:
     """one spatial sort of the (B,N,3) points of an SA level for furthest_point_sample / ball_query /
-    QueryAndGroup (their optional trailing argument); None where the library indexes nothing. Beyond the
-    reference: its kernels scan all N points each."""
-    return _ext.scene_index(xyz.detach().contiguous())
+    QueryAndGroup / three_nn (their optional trailing arguments); None where the library indexes nothing.
+    Beyond the reference: its kernels scan all N points each. The index of a tensor object is remembered
+    while that object lives and is not written to, so the FP module of a level finds the index its SA
+    module built (``cached_only``: look up, do not build)."""
+    if not xyz.is_cuda or not xyz.is_contiguous():
+        return None
+    key = id(xyz)
+    hit = _INDEX_CACHE.get(key)
+    if hit is not None and hit[0]() is xyz and hit[1] == xyz._version:
+        return hit[2]
+    if cached_only:
+        return None
+    index = _ext.scene_index(xyz.detach())
+    if index is not None:
+        if len(_INDEX_CACHE) > 64:
+            _INDEX_CACHE.clear()
+        _INDEX_CACHE[key] = (weakref.ref(xyz, lambda _r, _k=key: _INDEX_CACHE.pop(_k, None)), xyz._version, index)
+    return index
 
 
 class GatherOperation(Function):
@@ -85,19 +104,24 @@ class ThreeNN(Function):
     reference: pointnet2_utils.py:76-102 (the extension returns squared distances; sqrt here)"""
 
     @staticmethod
-    def forward(ctx, unknown: torch.Tensor, known: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    def forward(ctx, unknown: torch.Tensor, known: torch.Tensor, unknown_index: Optional[torch.Tensor] = None,
+                known_index: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """*_index: optional scene_index() of the two point sets (same result either way)"""
         assert unknown.is_contiguous() and known.is_contiguous()
         batch, n = unknown.shape[0], unknown.shape[1]
         m = known.shape[1]
         dist2 = _new(unknown, (batch, n, 3))
         idx = _new(unknown, (batch, n, 3), torch.int32)
-        _ext.three_nn_wrapper(batch, n, m, unknown, known, dist2, idx)
+        if known_index is None:
+            _ext.three_nn_wrapper(batch, n, m, unknown, known, dist2, idx)
+        else:
+            _ext.three_nn_indexed_wrapper(batch, n, m, unknown, known, unknown_index, known_index, dist2, idx)
         ctx.mark_non_differentiable(idx)
         return torch.sqrt(dist2), idx
 
     @staticmethod
     def backward(ctx, a=None, b=None):
-        return None, None
+        return None, None, None, None
 
 
 three_nn = ThreeNN.apply

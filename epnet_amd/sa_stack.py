@@ -234,10 +234,16 @@ class SAStack:
         b = self.batch
         # FP modules walk back up: unknown = xyz of the finer level, known = the coarser one
         xyzs = [xyz] + [L["sets"][parity]["new_xyz"] for L in self.levels]
+        # the scene index of level l's INPUT points is sets[parity]["index"] of level l
+        indices = [L["sets"][parity]["index"] for L in self.levels] + [None]
         for k, F in enumerate(self.fp_bufs):
             known = xyzs[len(self.levels) - k]
             unknown = xyzs[len(self.levels) - k - 1]
-            ext.three_nn_wrapper(b, F["n"], F["m"], unknown, known, F["dist2"], F["idx"])
+            k_index, u_index = indices[len(self.levels) - k], indices[len(self.levels) - k - 1]
+            if k_index is not None:
+                ext.three_nn_indexed_wrapper(b, F["n"], F["m"], unknown, known, u_index, k_index, F["dist2"], F["idx"])
+            else:
+                ext.three_nn_wrapper(b, F["n"], F["m"], unknown, known, F["dist2"], F["idx"])
             inv = 1.0 / (torch.sqrt(F["dist2"]) + 1e-8)      # pointnet2_modules.py:157-159
             weight = inv / torch.sum(inv, dim=2, keepdim=True)
             ext.three_interpolate_wrapper(b, F["c"], F["m"], F["n"], F["known_feats"], F["idx"], weight, F["out"])

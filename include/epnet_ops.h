@@ -156,6 +156,11 @@ int epnet_scene_index_build(int b, int n, const float *xyz, void *index, size_t 
 /* same contract as epnet_furthest_point_sampling (sampling_gpu.cu:211-253) */
 int epnet_furthest_point_sampling_indexed(int b, int n, int m, const float *xyz, const void *index,
                                           size_t index_bytes, float *temp, int *idx, epnet_stream_t stream);
+/* same contract as epnet_three_nn (interpolate_gpu.cu:55-74); known_index = scene index of `known` (NULL: plain
+ * path), unknown_index = scene index of `unknown` or NULL */
+int epnet_three_nn_indexed(int b, int n, int m, const float *unknown, const float *known, const void *unknown_index,
+                           size_t unknown_index_bytes, const void *known_index, size_t known_index_bytes, float *dist2,
+                           int *idx, epnet_stream_t stream);
 /* same contract as epnet_ball_query (ball_query_gpu.cu:48-66) */
 int epnet_ball_query_indexed(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
                              const void *index, size_t index_bytes, int *idx, epnet_stream_t stream);

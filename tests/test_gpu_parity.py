@@ -348,6 +348,42 @@ def test_three_nn_indexed_and_direct_paths_agree(oracle):
     assert l.epnet_three_nn_workspace_bytes(2, 256, 64) == 0
 
 
+@pytest.mark.parametrize("b,n,m,kind", [
+    (2, 16384, 4096, "kitti"), (2, 4096, 1024, "kitti"), (1, 5000, 1500, "ubox"), (2, 2048, 1030, "dup"),
+    (1, 40000, 3000, "kitti"), (2, 1024, 1024, "kitti"),
+    (2, 700, 1100, "kitti"),      # unknown set below the indexed range: known-index-only kernel
+    (2, 3000, 300, "kitti"),      # known set below it: plain path
+])
+def test_three_nn_over_scene_indices_matches_oracle(oracle, b, n, m, kind):
+    """epnet_three_nn_indexed with both point sets indexed (one wave per unknown bucket), with the known set only,
+    and with neither: indices and squared distances bit-equal to the oracle"""
+    from epnet_amd import pointnet2_cuda as ext
+    unknown = rand_cloud(b, n, seed=n + 1, kind=kind)
+    known = rand_cloud(b, m, seed=m + 2, kind=kind)
+    if kind == "dup":
+        known[:, 100:160] = unknown[:, :60]   # exact zero distances and ties between equal known rows
+    d_u, d_k = dev(unknown), dev(known)
+    o_d2, o_i = oracle.three_nn(unknown, known)
+    ui, ki = ext.scene_index(d_u), ext.scene_index(d_k)
+    for use_u in (True, False):
+        d2 = torch.full((b, n, 3), -1.0, device=DEV)
+        i = torch.full((b, n, 3), -1, dtype=torch.int32, device=DEV)
+        ext.three_nn_indexed_wrapper(b, n, m, d_u, d_k, ui if use_u else None, ki, d2, i)
+        np.testing.assert_array_equal(host(i), o_i)
+        np.testing.assert_array_equal(host(d2), o_d2)
+
+
+def test_scene_index_is_remembered_per_tensor_object():
+    from epnet_amd import pointnet2_utils as p2u
+    xyz = dev(rand_cloud(2, 2048, seed=9))
+    assert p2u.scene_index(xyz, cached_only=True) is None
+    index = p2u.scene_index(xyz)
+    assert index is not None and p2u.scene_index(xyz) is index and p2u.scene_index(xyz, cached_only=True) is index
+    xyz.add_(1.0)   # written to: the remembered index is stale and must not be served
+    assert p2u.scene_index(xyz, cached_only=True) is None
+    assert p2u.scene_index(dev(rand_cloud(2, 512, seed=9))) is None
+
+
 @pytest.mark.parametrize("b,c,m,n", [(2, 256, 64, 256), (2, 128, 1024, 4096), (1, 7, 50, 333), (2, 16, 9, 2), (2, 40, 4096, 16384)])
 def test_three_interpolate_and_grad(oracle, b, c, m, n):
     from epnet_amd import pointnet2_cuda as ext
