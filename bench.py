@@ -51,6 +51,9 @@ def parse():
                          "(bandwidth-bound) ball query + grouping of step k-1, double-buffered; 0: every step alone")
     ap.add_argument("--unfused", action="store_true", help="grouping as two group_points calls instead of group_concat")
     ap.add_argument("--no-shared-index", action="store_true", help="every op sorts the scene for itself")
+    ap.add_argument("--fused-sampling", action="store_true",
+                    help="epnet_sample_centres (FPS + gather of the centres in one kernel) instead of the reference module's "
+                         "sequence FPS, transpose, gather, transpose")
     ap.add_argument("--with-fp", action="store_true", help="also run the 4 three_nn + 4 three_interpolate FP ops")
     ap.add_argument("--cpu-scenes", type=int, default=int(os.environ.get("EPNET_BENCH_CPU_SCENES", "16")),
                     help="scenes in the cpu_baseline sample (0 = skip)")
@@ -130,6 +133,9 @@ def op_family(name, head):
     if name.startswith("furthest"):
         b, n, m = head[:3]
         return "fps N=%d M=%d" % (n, m), b * (n * 12 + m * 4)
+    if name.startswith("sample_centres"):  # FPS + the gather of the centres: the bytes of both
+        b, n, m = head[:3]
+        return "fps N=%d M=%d" % (n, m), b * (n * 12 + m * 4) + b * (m * 4 + 3 * n * 4 + 3 * m * 4)
     if name.startswith("gather_points_w"):
         b, c, n, m = head[:4]
         return "gather", b * (m * 4 + c * n * 4 + c * m * 4)
@@ -208,7 +214,8 @@ def main():
         xyz = torch.stack([fn(args.points, scene_shard.scene_seed(1, i)) for i in ids]).to(dev)  # inputs resident in HBM
         stack = sa_stack.SAStack(batch, n=args.points, device=dev, with_fp=args.with_fp, seed=rank,
                                  overlap=not args.no_overlap, fused=not args.unfused,
-                                 shared_index=not args.no_shared_index, pipelined=bool(args.pipelined))
+                                 shared_index=not args.no_shared_index, pipelined=bool(args.pipelined),
+                                 fused_sampling=args.fused_sampling)
         if args.no_graph:
             step = lambda: stack.step(xyz)
         else:

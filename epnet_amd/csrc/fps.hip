@@ -355,12 +355,16 @@ __device__ __forceinline__ void set_rank(VH &rk2, int j, unsigned r) {  // j is 
 // (distance bits << 32 | (0x3FFF - rank) << 4 | wave): the larger distance wins, equal distances go to the
 // smaller reference rank -- and after the round's single barrier the winner is read back with two
 // dependent LDS loads (key, then that wave's coordinates), no cross-lane reduction at all.
-template <int kW, int PPT, typename VF, typename VI, typename VH>
+// kCtr: also emit the selected points' coordinates (ctr, m x 3 floats): the gather that follows the sampling
+// in an SA module (pointnet2_modules.py:39-45) comes for free, the round's winner is in registers anyway.
+template <int kW, int PPT, bool kCtr, typename VF, typename VI, typename VH>
 __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, const VF &z, VI &t, const VH &rk2,
-                                           float cx, float cy, float cz, int *__restrict__ idxs) {
+                                           float cx, float cy, float cz, int *__restrict__ idxs,
+                                           float *__restrict__ ctr) {
     __shared__ unsigned long long s_key[3];
     __shared__ float4 s_rec[2][16];
     __shared__ int s_idx[kIdxBufP];
+    __shared__ float s_ctr[kCtr ? kIdxBufP * 3 : 1];
     const int q = threadIdx.x;
     const int lane = q & 63, wave = q >> 6;
     const int sub = lane & (PPT - 1);  // the slot this lane summarises (for its own part)
@@ -387,6 +391,7 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
     }
     if (q < 3) s_key[q] = 0ull;
     if (q == 0) s_idx[0] = 0;  // rank 0 == point 0
+    if (kCtr && q < 3) s_ctr[q] = q == 0 ? cx : (q == 1 ? cy : cz);
     __syncthreads();
 
     // a strictly serial chain: when it shares a SIMD with a wide kernel (software-pipelined SA stack), every
@@ -476,9 +481,14 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
         if (wave == 0) {
             s_idx[it & (kIdxBufP - 1)] = (int)(0x3FFFu - (klo >> 4));  // all lanes, same word; converted at the flush
             if (lane == 0) s_key[kb2] = 0ull;
+            if (kCtr && lane < 3) s_ctr[(it & (kIdxBufP - 1)) * 3 + lane] = lane == 0 ? cx : (lane == 1 ? cy : cz);
             if ((it & (kIdxBufP - 1)) == kIdxBufP - 1) {
                 const int base = it - (kIdxBufP - 1);
                 for (int e = lane; e < kIdxBufP; e += 64) idxs[base + e] = unrank14((unsigned)s_idx[e]);
+                if (kCtr) {
+#pragma unroll 1
+                    for (int e = lane; e < kIdxBufP * 3; e += 64) ctr[(size_t)base * 3 + e] = s_ctr[e];
+                }
             }
         }
         EPNET_STAMP(t5);
@@ -490,6 +500,10 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
     if (wave == 0) {
         const int base = (m - 1) & ~(kIdxBufP - 1);
         for (int e = lane; base + e < m; e += 64) idxs[base + e] = unrank14((unsigned)s_idx[e]);
+        if (kCtr) {
+#pragma unroll 1
+            for (int e = lane; e < (m - base) * 3; e += 64) ctr[(size_t)base * 3 + e] = s_ctr[e];
+        }
     }
 }
 
@@ -543,7 +557,7 @@ __global__ __launch_bounds__(64 * kW) void fps_pruned_kernel(int n, int m, const
             set_rank(rk2, j, 0xFFFFu);
         }
     }
-    fps_rounds<kW, PPT>(m, x, y, z, t, rk2, xyz[0], xyz[1], xyz[2], idxs);
+    fps_rounds<kW, PPT, false>(m, x, y, z, t, rk2, xyz[0], xyz[1], xyz[2], idxs, nullptr);
     if (temp) {
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
@@ -555,9 +569,10 @@ __global__ __launch_bounds__(64 * kW) void fps_pruned_kernel(int n, int m, const
 
 // Same rounds over a scene index built beforehand (spatial.h: cell-sorted float4 copy x, y, z, original index;
 // padding entries carry index -1). Needs no dynamic LDS, so it shares a CU with the bandwidth-bound kernels.
-template <int kW, int PPT>
+template <int kW, int PPT, bool kCtr>
 __global__ __launch_bounds__(64 * kW) void fps_indexed_kernel(int n, int m, const float4 *__restrict__ sorted,
-                                                              float *__restrict__ temp, int *__restrict__ idxs) {
+                                                              float *__restrict__ temp, int *__restrict__ idxs,
+                                                              float *__restrict__ ctr) {
     typedef float vecf __attribute__((ext_vector_type(PPT)));
     typedef int veci __attribute__((ext_vector_type(PPT)));
     constexpr int NP = 64 * kW * PPT;
@@ -567,6 +582,7 @@ __global__ __launch_bounds__(64 * kW) void fps_indexed_kernel(int n, int m, cons
     sorted += (size_t)blockIdx.x * NP;
     if (temp) temp += (size_t)blockIdx.x * n;
     idxs += (size_t)blockIdx.x * m;
+    if (kCtr) ctr += (size_t)blockIdx.x * m * 3;
     typedef int vech __attribute__((ext_vector_type(PPT / 2)));
     vecf x, y, z;
     veci t;
@@ -593,7 +609,7 @@ __global__ __launch_bounds__(64 * kW) void fps_indexed_kernel(int n, int m, cons
         }
     }
     __syncthreads();
-    fps_rounds<kW, PPT>(m, x, y, z, t, rk2, s_first[0], s_first[1], s_first[2], idxs);
+    fps_rounds<kW, PPT, kCtr>(m, x, y, z, t, rk2, s_first[0], s_first[1], s_first[2], idxs, ctr);
     if (temp) {
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
@@ -946,37 +962,81 @@ extern "C" int epnet_furthest_point_sampling(int b, int n, int m, const float *x
     return check_launch("furthest_point_sampling");
 }
 
+// rows of the (B,N,3) cloud picked by idx (B,M): the centres of an SA level
+__global__ __launch_bounds__(256) void gather_centres_kernel(int n, int m, const float *__restrict__ xyz,
+                                                             const int *__restrict__ idx, float *__restrict__ out) {
+    const int bs = blockIdx.y;
+    const int e = blockIdx.x * 256 + threadIdx.x;  // element of the (m, 3) output
+    if (e >= m * 3) return;
+    const int i = e / 3, a = e - i * 3;
+    out[(size_t)bs * m * 3 + e] = xyz[((size_t)bs * n + idx[(size_t)bs * m + i]) * 3 + a];
+}
+
+// shared by the two entry points below; new_xyz may be NULL
+static int fps_over_index(int b, int n, int m, const float *xyz, const void *index, size_t index_bytes, float *temp, int *idx,
+                          float *new_xyz, hipStream_t s) {
+    const size_t need = scene_index_bytes(b, n);
+    bool centres_done = false;
+    int rc;
+    // n <= 1024: the reference block size (hence the tie-break rank) depends on n; the one-wave kernel handles it
+    if (need == 0 || !index || n <= 1024 || m <= 1 || (n > 16384 && !temp)) {
+        rc = epnet_furthest_point_sampling(b, n, m, xyz, temp, idx, (epnet_stream_t)s);
+    } else {
+        EPNET_REQUIRE(idx);
+        if (index_bytes < need) return EPNET_ENOMEM;
+        const float4 *sorted = (const float4 *)index;
+        dim3 grid(b);
+        if (n > 16384) {  // beyond the register file: bucket summaries in registers, points re-read from the index
+            EPNET_REQUIRE(xyz);
+            const int np = scene_index_np(n);
+            hipLaunchKernelGGL(pruned::fps_bigscene_kernel, grid, dim3(pruned::kBigThreads), 0, s, n, np, m, xyz, sorted,
+                               (const float *)(sorted + (size_t)b * np), temp, idx);
+        } else {
+            static const int wide = getenv("EPNET_FPS_WIDE") ? atoi(getenv("EPNET_FPS_WIDE")) : 0;
+#define EPNET_FPS_INDEXED(W_, P_)                                                                                          \
+    do {                                                                                                                   \
+        if (new_xyz)                                                                                                       \
+            hipLaunchKernelGGL((pruned::fps_indexed_kernel<W_, P_, true>), grid, dim3(64 * W_), 0, s, n, m, sorted, temp, \
+                               idx, new_xyz);                                                                              \
+        else                                                                                                               \
+            hipLaunchKernelGGL((pruned::fps_indexed_kernel<W_, P_, false>), grid, dim3(64 * W_), 0, s, n, m, sorted, temp, \
+                               idx, (float *)nullptr);                                                                     \
+    } while (0)
+            switch (scene_index_np(n)) {
+                case 2048: EPNET_FPS_INDEXED(4, 8); break;
+                case 4096: EPNET_FPS_INDEXED(4, 16); break;
+                case 8192: EPNET_FPS_INDEXED(4, 32); break;
+                default:
+                    if (wide) EPNET_FPS_INDEXED(16, 16);
+                    else EPNET_FPS_INDEXED(8, 32);
+                    break;
+            }
+#undef EPNET_FPS_INDEXED
+            centres_done = new_xyz != nullptr;
+        }
+        rc = check_launch("furthest_point_sampling");
+    }
+    if (rc || !new_xyz || centres_done) return rc;
+    if (m == 0) return EPNET_OK;
+    EPNET_REQUIRE(xyz && b <= 65535);
+    hipLaunchKernelGGL(gather_centres_kernel, dim3(div_up(m * 3, 256), b), dim3(256), 0, s, n, m, xyz, idx, new_xyz);
+    return check_launch("sample_centres gather");
+}
+
 extern "C" int epnet_furthest_point_sampling_indexed(int b, int n, int m, const float *xyz, const void *index,
                                                      size_t index_bytes, float *temp, int *idx,
                                                      epnet_stream_t stream) {
-    const size_t need = scene_index_bytes(b, n);
-    // n <= 1024: the reference block size (hence the tie-break rank) depends on n; the one-wave kernel handles it
-    if (need == 0 || !index || n <= 1024 || m <= 1 || (n > 16384 && !temp))
-        return epnet_furthest_point_sampling(b, n, m, xyz, temp, idx, stream);
-    EPNET_REQUIRE(idx);
-    if (index_bytes < need) return EPNET_ENOMEM;
-    hipStream_t s = (hipStream_t)stream;
-    const float4 *sorted = (const float4 *)index;
-    dim3 grid(b);
-    if (n > 16384) {  // beyond the register file: bucket summaries in registers, points re-read from the index
-        EPNET_REQUIRE(xyz);
-        const int np = scene_index_np(n);
-        hipLaunchKernelGGL(pruned::fps_bigscene_kernel, grid, dim3(pruned::kBigThreads), 0, s, n, np, m, xyz, sorted,
-                           (const float *)(sorted + (size_t)b * np), temp, idx);
-        return check_launch("furthest_point_sampling");
-    }
-    static const int wide = getenv("EPNET_FPS_WIDE") ? atoi(getenv("EPNET_FPS_WIDE")) : 0;
-#define EPNET_FPS_INDEXED(W_, P_) \
-    hipLaunchKernelGGL((pruned::fps_indexed_kernel<W_, P_>), grid, dim3(64 * W_), 0, s, n, m, sorted, temp, idx)
-    switch (scene_index_np(n)) {
-        case 2048: EPNET_FPS_INDEXED(4, 8); break;
-        case 4096: EPNET_FPS_INDEXED(4, 16); break;
-        case 8192: EPNET_FPS_INDEXED(4, 32); break;
-        default:
-            if (wide) EPNET_FPS_INDEXED(16, 16);
-            else EPNET_FPS_INDEXED(8, 32);
-            break;
-    }
-#undef EPNET_FPS_INDEXED
-    return check_launch("furthest_point_sampling");
+    return fps_over_index(b, n, m, xyz, index, index_bytes, temp, idx, nullptr, (hipStream_t)stream);
+}
+
+// furthest point sampling from a fresh state AND the gather of the selected coordinates, i.e. the head of an SA module
+// (pointnet2_modules.py:39-45: furthest_point_sample, then gather_operation on the flipped cloud, flipped back):
+// idx (B,M) and new_xyz (B,M,3) = xyz[b, idx[b,i], :]. temp: running-distance scratch (B,N) or NULL (then every
+// distance starts at 1e10 as pointnet2_utils.py:26 sets it; allowed for 64 <= n <= 16384); index may be NULL.
+extern "C" int epnet_sample_centres(int b, int n, int m, const float *xyz, const void *index, size_t index_bytes,
+                                    float *temp, int *idx, float *new_xyz, epnet_stream_t stream) {
+    EPNET_REQUIRE(b >= 0 && n >= 1 && m >= 0);
+    if (b == 0 || m == 0) return EPNET_OK;
+    EPNET_REQUIRE(xyz && idx && new_xyz);
+    return fps_over_index(b, n, m, xyz, index, index_bytes, temp, idx, new_xyz, (hipStream_t)stream);
 }

@@ -182,6 +182,18 @@ def furthest_point_sampling_indexed_wrapper(b, n, m, points, index, temp, idx):
     return 1
 
 
+def sample_centres_wrapper(b, n, m, points, index, idx, new_xyz):
+    """furthest_point_sampling from a fresh state + gather of the selected rows: idx (B,M) and new_xyz (B,M,3)"""
+    pp, pi, pn = dev_ptr(points, "points", _F), dev_ptr(idx, "idx", _I), dev_ptr(new_xyz, "new_xyz", _F)
+    need(points, b * n * 3, "points"); need(idx, b * m, "idx"); need(new_xyz, b * m * 3, "new_xyz")
+    px, nb = _index_args(index, points)
+    temp = None if 64 <= n <= 16384 else torch.full((b, n), 1e10, dtype=_F, device=points.device)
+    with on_device_of(points) as s:
+        _lib.check(_lib.lib().epnet_sample_centres(b, n, m, pp, px, nb, None if temp is None else temp.data_ptr(), pi, pn, s),
+                   "sample_centres")
+    return 1
+
+
 def three_nn_indexed_wrapper(b, n, m, unknown, known, unknown_index, known_index, dist2, idx):
     """three_nn_wrapper over scene indices of `known` and (optionally) of `unknown` (same results)"""
     pu, pk = dev_ptr(unknown, "unknown", _F), dev_ptr(known, "known", _F)

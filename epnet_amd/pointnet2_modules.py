@@ -41,9 +41,12 @@ class _PointnetSAModuleBase(nn.Module):
         # one spatial sort of the level's points serves the sampling and every ball query of the level
         index = pointnet2_utils.scene_index(xyz) if self.npoint is not None and xyz.is_cuda else None
         if new_xyz is None and self.npoint is not None:
-            idx = pointnet2_utils.furthest_point_sample(xyz, self.npoint, index)
-            channels_first = xyz.transpose(1, 2).contiguous()
-            new_xyz = pointnet2_utils.gather_operation(channels_first, idx).transpose(1, 2).contiguous()
+            if xyz.is_cuda and xyz.is_contiguous() and not (torch.is_grad_enabled() and xyz.requires_grad):
+                idx, new_xyz = pointnet2_utils.sample_and_gather(xyz, self.npoint, index)  # one kernel, same values
+            else:
+                idx = pointnet2_utils.furthest_point_sample(xyz, self.npoint, index)
+                channels_first = xyz.transpose(1, 2).contiguous()
+                new_xyz = pointnet2_utils.gather_operation(channels_first, idx).transpose(1, 2).contiguous()
 
         pooled = []
         for grouper, mlp in zip(self.groupers, self.mlps):

@@ -74,6 +74,19 @@ def scene_index(xyz: torch.Tensor, cached_only: bool = False) -> Optional[torch.
     return index
 
 
+def sample_and_gather(xyz: torch.Tensor, npoint: int, index: Optional[torch.Tensor] = None):
+    """the head of an SA module in one call: ``idx = furthest_point_sample(xyz, npoint)`` and
+    ``new_xyz = gather_operation(xyz.transpose(1, 2), idx).transpose(1, 2)`` (pointnet2_modules.py:39-45) -- the
+    sampling kernel has every selected point in registers, so the centres come with the indices. Same values;
+    no gradient flows to xyz here (use the composition when the coordinates need one)."""
+    assert xyz.is_contiguous()
+    batch, n = xyz.shape[0], xyz.shape[1]
+    idx = _new(xyz, (batch, npoint), torch.int32)
+    new_xyz = _new(xyz, (batch, npoint, 3))
+    _ext.sample_centres_wrapper(batch, n, npoint, xyz.detach(), index, idx, new_xyz)
+    return idx, new_xyz
+
+
 class GatherOperation(Function):
     """features (B,C,N), idx (B,npoint) int32 -> (B,C,npoint). reference: pointnet2_utils.py:39-70"""
 

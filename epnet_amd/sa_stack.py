@@ -64,7 +64,7 @@ def fp_algorithmic_bytes(fp=RPN_FP):
 class SAStack:
     def __init__(self, batch, n=16384, device="cuda", npoints=RPN_NPOINTS, radii=RPN_RADII, nsamples=RPN_NSAMPLES,
                  feat_channels=RPN_FEAT_CHANNELS, with_fp=False, fp=RPN_FP, seed=0, overlap=True, fused=True,
-                 shared_index=True, pipelined=False):
+                 shared_index=True, pipelined=False, fused_sampling=False):
         self.batch, self.n = batch, n
         # overlap: FPS/gather of level l+1 depend only on the centres of level l (never on features), so
         # the sampling chain runs ahead on the launch stream while ball query + grouping of each level
@@ -73,6 +73,9 @@ class SAStack:
         self.fused = fused                # grouped [xyz - centre ; features] from one kernel (epnet_group_concat)
         self.shared_index = shared_index  # one scene index per level for FPS + both ball queries
         self.pipelined = pipelined
+        # FPS + centre gather in one kernel (epnet_sample_centres): fewer launches for eager callers (the SA module
+        # uses it); under a HIP graph it was measured equal to the reference's op-by-op sequence, which stays the default
+        self.fused_sampling = fused_sampling
         self.tail_scales = int(os.environ.get("EPNET_SA_TAIL_SCALES", "0"))
         self.side = None
         self.npoints, self.radii, self.nsamples, self.feat_channels = npoints, radii, nsamples, feat_channels
@@ -130,14 +133,19 @@ class SAStack:
         P = L["sets"][parity]
         if P["index"] is not None and not index_built:
             ext.scene_index_build_wrapper(b, n, cur_xyz, P["index"])
-        L["xyz_t"].copy_(cur_xyz.transpose(1, 2))            # pointnet2_modules.py:30
-        L["temp"].fill_(1e10)                                # pointnet2_utils.py:26
-        if P["index"] is not None:
-            ext.furthest_point_sampling_indexed_wrapper(b, n, m, cur_xyz, P["index"], L["temp"], L["fps_idx"])
-        else:
-            ext.furthest_point_sampling_wrapper(b, n, m, cur_xyz, L["temp"], L["fps_idx"])
-        ext.gather_points_wrapper(b, 3, n, m, L["xyz_t"], L["fps_idx"], L["new_xyz_t"])
-        P["new_xyz"].copy_(L["new_xyz_t"].transpose(1, 2))    # pointnet2_modules.py:42-45
+        if self.fused_sampling:   # FPS + gather of the centres in one kernel (epnet_sample_centres)
+            if not self.fused:
+                L["xyz_t"].copy_(cur_xyz.transpose(1, 2))
+            ext.sample_centres_wrapper(b, n, m, cur_xyz, P["index"], L["fps_idx"], P["new_xyz"])
+        else:                     # the reference module's sequence, op by op
+            L["xyz_t"].copy_(cur_xyz.transpose(1, 2))            # pointnet2_modules.py:30
+            L["temp"].fill_(1e10)                                # pointnet2_utils.py:26
+            if P["index"] is not None:
+                ext.furthest_point_sampling_indexed_wrapper(b, n, m, cur_xyz, P["index"], L["temp"], L["fps_idx"])
+            else:
+                ext.furthest_point_sampling_wrapper(b, n, m, cur_xyz, L["temp"], L["fps_idx"])
+            ext.gather_points_wrapper(b, 3, n, m, L["xyz_t"], L["fps_idx"], L["new_xyz_t"])
+            P["new_xyz"].copy_(L["new_xyz_t"].transpose(1, 2))    # pointnet2_modules.py:42-45
         return P["new_xyz"]
 
     # ---- stage G: neighbour search + grouping of one level

@@ -156,6 +156,11 @@ int epnet_scene_index_build(int b, int n, const float *xyz, void *index, size_t 
 /* same contract as epnet_furthest_point_sampling (sampling_gpu.cu:211-253) */
 int epnet_furthest_point_sampling_indexed(int b, int n, int m, const float *xyz, const void *index,
                                           size_t index_bytes, float *temp, int *idx, epnet_stream_t stream);
+/* the head of an SA module in one call (pointnet2_modules.py:39-45): furthest point sampling from a fresh state
+ * (all running distances 1e10, pointnet2_utils.py:26) and new_xyz (b,m,3) = the selected rows of xyz. temp = scratch
+ * (b,n) or NULL (allowed for 64 <= n <= 16384); index = scene index of xyz or NULL */
+int epnet_sample_centres(int b, int n, int m, const float *xyz, const void *index, size_t index_bytes, float *temp,
+                         int *idx, float *new_xyz, epnet_stream_t stream);
 /* same contract as epnet_three_nn (interpolate_gpu.cu:55-74); known_index = scene index of `known` (NULL: plain
  * path), unknown_index = scene index of `unknown` or NULL */
 int epnet_three_nn_indexed(int b, int n, int m, const float *unknown, const float *known, const void *unknown_index,

@@ -134,6 +134,23 @@ def test_fps_over_scene_index_matches_oracle(oracle, b, n, m, kind):
     np.testing.assert_array_equal(host(temp), o_temp)
 
 
+@pytest.mark.parametrize("b,n,m,kind", [
+    (2, 16384, 4096, "kitti"), (2, 16384, 1500, "dup"), (2, 4096, 1024, "kitti"), (2, 2048, 2047, "ubox"),
+    (2, 1024, 256, "kitti"), (3, 256, 64, "kitti"), (2, 40, 7, "ubox"), (1, 20000, 33, "kitti"), (2, 5000, 1, "ubox"),
+])
+def test_sample_and_gather_equals_fps_then_gather(oracle, b, n, m, kind):
+    """epnet_sample_centres: the indices of FPS from a fresh state and exactly the rows they select"""
+    from epnet_amd import pointnet2_utils as p2u
+    xyz = rand_cloud(b, n, seed=900 + n, kind=kind)
+    d_xyz = dev(xyz)
+    o_idx = oracle.furthest_point_sampling(xyz, m)
+    want = np.take_along_axis(xyz, o_idx[..., None].astype(np.int64), axis=1)
+    for index in (p2u.scene_index(d_xyz), None):
+        idx, new_xyz = p2u.sample_and_gather(d_xyz, m, index)
+        np.testing.assert_array_equal(host(idx), o_idx)
+        np.testing.assert_array_equal(host(new_xyz), want)
+
+
 def test_fps_over_scene_index_ties(oracle):
     from epnet_amd import pointnet2_cuda as ext
     rng = np.random.default_rng(5)
