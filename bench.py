@@ -61,34 +61,66 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(kind, n_points, scenes):
-    """the oracle's scalar port of the same op stack, one core, on `scenes` scenes"""
+_CPU_JOBS = {}  # inputs of the CPU baselines, prepared in the parent and inherited by forked workers
+
+
+def _cpu_prepare(kind, n_points, seeds):
     import numpy as np
     from epnet_amd import sa_stack, synth
+    rng = np.random.default_rng(0)
+    _CPU_JOBS["feats"] = [None if c == 0 else rng.standard_normal((1, c, nn)).astype(np.float32)
+                          for c, nn in zip(sa_stack.RPN_FEAT_CHANNELS, (n_points,) + sa_stack.RPN_NPOINTS[:-1])]
+    for s in seeds:
+        _CPU_JOBS[s] = synth.scenes(kind, 1, n_points, seed=s).numpy()
+
+
+def _cpu_scene_seconds(seed):
+    """the oracle's scalar port of the same op stack on one prepared scene; returns its CPU seconds"""
+    import numpy as np
+    from epnet_amd import sa_stack
+    from oracle import oracle
+    feats, cur = _CPU_JOBS["feats"], _CPU_JOBS[seed]
+    t0 = time.perf_counter()
+    for lvl, m in enumerate(sa_stack.RPN_NPOINTS):
+        cur_t = np.ascontiguousarray(cur.transpose(0, 2, 1))
+        idx = oracle.furthest_point_sampling(cur, m)
+        new_xyz = np.ascontiguousarray(oracle.gather_points(cur_t, idx).transpose(0, 2, 1))
+        for radius, ns in zip(sa_stack.RPN_RADII[lvl], sa_stack.RPN_NSAMPLES[lvl]):
+            bq = oracle.ball_query(radius, ns, cur, new_xyz)
+            oracle.group_points(cur_t, bq)
+            if feats[lvl] is not None:
+                oracle.group_points(feats[lvl], bq)
+        cur = new_xyz
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(kind, n_points, scenes):
+    """one core: `scenes` scenes one after the other"""
     from oracle import oracle
     oracle.build()
-    rng = np.random.default_rng(0)
-    t_total = 0.0
-    for s in range(scenes):
-        xyz = synth.scenes(kind, 1, n_points, seed=1000 + s).numpy()
-        feats = [None if c == 0 else rng.standard_normal((1, c, nn)).astype(np.float32)
-                 for c, nn in zip(sa_stack.RPN_FEAT_CHANNELS, (n_points,) + sa_stack.RPN_NPOINTS[:-1])]
-        t0 = time.perf_counter()
-        cur = xyz
-        for lvl, m in enumerate(sa_stack.RPN_NPOINTS):
-            cur_t = np.ascontiguousarray(cur.transpose(0, 2, 1))
-            idx = oracle.furthest_point_sampling(cur, m)
-            new_xyz = np.ascontiguousarray(oracle.gather_points(cur_t, idx).transpose(0, 2, 1))
-            for radius, ns in zip(sa_stack.RPN_RADII[lvl], sa_stack.RPN_NSAMPLES[lvl]):
-                bq = oracle.ball_query(radius, ns, cur, new_xyz)
-                oracle.group_points(cur_t, bq)
-                if feats[lvl] is not None:
-                    oracle.group_points(feats[lvl], bq)
-            cur = new_xyz
-        t_total += time.perf_counter() - t0
+    seeds = [1000 + s for s in range(scenes)]
+    _cpu_prepare(kind, n_points, seeds)
+    t_total = sum(_cpu_scene_seconds(s) for s in seeds)
     return {"value": scenes * n_points / t_total, "unit": "points/s", "cores": 1, "kind": "port",
             "sample": "%d %s scenes of %d points through the same 4-level SA op stack, oracle/epnet_oracle.c, "
                       "%.1f s of CPU time on %d-core host" % (scenes, kind, n_points, t_total, os.cpu_count())}
+
+
+def cpu_baseline_multicore(kind, n_points, procs):
+    """the same port, one scene per worker process at a time (the stack shards by scene on the CPU too); the
+    workers are forked BEFORE this process touches the GPU and inherit the prepared inputs"""
+    import multiprocessing as mp
+    from oracle import oracle
+    oracle.build()
+    seeds = [2000 + s for s in range(2 * procs)]
+    _cpu_prepare(kind, n_points, seeds)
+    with mp.get_context("fork").Pool(procs) as pool:
+        pool.map(_cpu_scene_seconds, seeds[:procs], chunksize=1)   # start-up: workers load the oracle
+        t0 = time.perf_counter()
+        pool.map(_cpu_scene_seconds, seeds, chunksize=1)
+        wall = time.perf_counter() - t0
+    return {"value": len(seeds) * n_points / wall, "unit": "points/s", "cores": procs, "kind": "port",
+            "sample": "%d %s scenes over %d worker processes, %.1f s wall" % (len(seeds), kind, procs, wall)}
 
 
 class OpTimer:
@@ -188,6 +220,11 @@ def main():
 
     from epnet_amd import scene_shard
     rank, local_rank, world = scene_shard.env_world()
+    # CPU baselines first: the multi-core one forks workers, which must happen before this process touches the GPU
+    cpu = cpu_multi = None
+    if rank == 0 and world == 1 and args.cpu_scenes > 0:
+        cpu_multi = cpu_baseline_multicore(args.kind, args.points, max(1, min(16, os.cpu_count() or 1)))
+        cpu = cpu_baseline(args.kind, args.points, args.cpu_scenes)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
     # one process per GPU. EPNET_BENCH_DEVICE / EPNET_BENCH_BACKEND exist only to rehearse the N > 1 code
@@ -280,9 +317,18 @@ def main():
         e, _, _ = time_stack(bsz, args.steps, args.warmup)
         sweep[str(bsz)] = {"ms_per_step": round(e / args.steps * 1e3, 4), "points_per_s": round(bsz * args.points * args.steps / e, 1)}
 
-    cpu = None
-    if rank == 0 and world == 1 and args.cpu_scenes > 0:
-        cpu = cpu_baseline(args.kind, args.points, args.cpu_scenes)
+    # achievable secondary denominator: a plain device-to-device copy of 2 GiB on this box
+    src = torch.empty((1 << 29,), dtype=torch.float32, device=dev)
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    copy_gbs = 5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9   # bytes read + bytes written
+    del src, dst
 
     if rank == 0:
         line = {
@@ -298,7 +344,9 @@ def main():
                        "scenes_per_gpu": args.batch, "software_pipelined": bool(args.pipelined), "points_per_scene": args.points, "parallelism": "scene-parallel x%d" % world},
             "points_per_s_per_gpu": round(value / world, 1),
             "stack_algorithmic_GBps_per_gpu": round(stack_gbs, 2), "stack_hbm_frac": round(stack_gbs / HBM_PEAK_GBS, 6),
+            "device_copy_GBps": round(copy_gbs, 1), "stack_frac_of_device_copy": round(stack_gbs / copy_gbs, 6),
             "roofline": roofline, "roofline_hbm_bound": roofline_hbm, "kernels": kernels, "cpu_baseline": cpu,
+            "cpu_baseline_multicore": cpu_multi,
         }
         if sweep:
             line["sweep"] = sweep

@@ -101,7 +101,7 @@ def main():
         report("group_points_grad", {"B": bsz, "C": 96, "N": 4096, "M": 1024, "ns": 32}, ms, bsz * (96 * 1024 * 32 * 4 + 1024 * 32 * 4 + 96 * 4096 * 4))
     # ---- BASELINE config 5: dense 65536-point scenes, one SA level with nsample = 64 (ball-query stress)
     for bsz in (1, 16):
-        n, m, ns, c, radius = 65536, 16384, 64, 32, 0.4
+        n, m, ns, c, radius = 65536, 16384, 64, 64, 0.5
         xyz = synth.scenes("kitti", bsz, n, seed=9).to(dev)
         index = torch.empty((p2.scene_index_bytes(bsz, n),), dtype=torch.uint8, device=dev)
         ms = timeit(lambda: p2.scene_index_build_wrapper(bsz, n, xyz, index))
@@ -122,6 +122,9 @@ def main():
         ms = timeit(lambda: p2.group_concat_wrapper(bsz, c, n, m, ns, xyz, new_xyz, feats, bq, grouped, True))
         report("group_concat", {"B": bsz, "C": c, "N": n, "M": m, "ns": ns}, ms,
                bsz * (2 * m * ns * 4 + 3 * n * 4 + c * n * 4 + (3 + c) * m * ns * 4))
+        gx = torch.empty((bsz, 3, m, ns), device=dev)
+        ms = timeit(lambda: p2.group_concat_wrapper(bsz, 0, n, m, ns, xyz, new_xyz, None, bq, gx, True))
+        report("group_concat", {"B": bsz, "C": 0, "N": n, "M": m, "ns": ns}, ms, bsz * (m * ns * 4 + 3 * n * 4 + 3 * m * ns * 4))
 
 
 if __name__ == "__main__":
