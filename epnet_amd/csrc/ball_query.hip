@@ -222,109 +222,89 @@ __device__ __forceinline__ bool box_near(const float *__restrict__ bx, float cx,
 // One wave per centre. Two levels of boxes: the lanes test the quad boxes (256 points each), then -- 16 candidate
 // quads at a time -- the 4 bucket boxes of each candidate quad, then the 64 points of every near bucket. A ball holds
 // a handful of points (median 1-2 on KITTI-like scenes), so the hits are appended to a 64-entry list and ordered
-// by counting; only a ball with more than 64 hits takes the second pass through the N-bit bitmap.
+// by counting; only a ball with more than 64 hits takes a second walk through the N-bit bitmap.
+// The K scales of an MSG level (same centres, same points, nested balls) share ONE walk: boxes are tested against
+// the largest radius and every distance is computed once.
 // DPL = bitmap dwords per lane = np / 2048 (np >= 2048)
-template <int DPL>
-__global__ __launch_bounds__(kQThreads) void bq_query_kernel(int np, int m, float radius2, int nsample,
-                                                             const float *__restrict__ new_xyz,
-                                                             const float4 *__restrict__ sorted,
-                                                             const float *__restrict__ boxes,
-                                                             const float *__restrict__ qboxes, int *__restrict__ idx) {
-    __shared__ unsigned s_bits[kQThreads / 64][64 * DPL];
-    __shared__ int s_quads[kQThreads / 64][64];
-    __shared__ int s_hits[kQThreads / 64][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int bs = blockIdx.y;
-    const int ci = blockIdx.x * (kQThreads / 64) + wave;
-    if (ci >= m) return;  // wave-uniform; no block-level barrier below
-    sorted += (size_t)bs * np;
-    boxes += (size_t)bs * (np / 64) * 6;
-    qboxes += (size_t)bs * (np / 256) * 6;
-    const float *c = new_xyz + ((size_t)bs * m + ci) * 3;
-    const float cx = c[0], cy = c[1], cz = c[2];
-    int *out = idx + ((size_t)bs * m + ci) * nsample;
-    unsigned *bits = s_bits[wave];
-    int *quads = s_quads[wave], *hits = s_hits[wave];
 
-    const int nq = np >> 8;  // quads (>= 8)
-    int cnt = 0;             // hits so far (wave-uniform)
-    bool bitmap = false;
-    // the 64 points of one near bucket
+// the candidate walk: visit(p, d2) for the 64 points p (one per lane) of every bucket whose box is nearer than r2
+template <int DPL, typename F>
+__device__ __forceinline__ void bq_walk(int lane, int np, float r2, float cx, float cy, float cz,
+                                        const float4 *__restrict__ sorted, const float *__restrict__ boxes,
+                                        const float *__restrict__ qboxes, int *quads, F &&visit) {
     auto scan_bucket = [&](int bb) {
         const float4 p = sorted[(bb << 6) + lane];
         const float dx = cx - p.x, dy = cy - p.y, dz = cz - p.z;
-        const float d2 = dx * dx + dy * dy + dz * dz;
-        const bool hit = d2 < radius2;
-        if (!bitmap) {
-            const unsigned long long hm = __ballot(hit);
-            if (hm) {
-                const int pos = cnt + popc_below(hm);
-                if (hit && pos < 64) hits[pos] = __float_as_int(p.w);
-                cnt += (int)__popcll(hm);
+        visit(p, dx * dx + dy * dy + dz * dz);
+    };
+    if constexpr (DPL <= 2) {  // <= 64 buckets: one round over the bucket boxes, no second level
+        const bool bnear = lane < (np >> 6) && box_near(boxes + lane * 6, cx, cy, cz, r2);
+        unsigned long long cand = __ballot(bnear);
+        while (cand) {
+            const int bb = (int)__builtin_ctzll(cand);
+            cand &= cand - 1ull;
+            scan_bucket(bb);
+        }
+    } else {
+        const int nq = np >> 8;
+        for (int q0 = 0; q0 < nq; q0 += 64) {
+            const int qd = q0 + lane;
+            const bool qnear = qd < nq && box_near(qboxes + qd * 6, cx, cy, cz, r2);
+            const unsigned long long qmask = __ballot(qnear);
+            if (!qmask) continue;
+            const int nqc = (int)__popcll(qmask);
+            if (qnear) quads[popc_below(qmask)] = qd;
+            __builtin_amdgcn_wave_barrier();
+            for (int s0 = 0; s0 < nqc; s0 += 16) {
+                const int slot = s0 + (lane >> 2);
+                int bid = 0;
+                bool bnear = false;
+                if (slot < nqc) {
+                    bid = quads[slot] * 4 + (lane & 3);
+                    bnear = box_near(boxes + bid * 6, cx, cy, cz, r2);
+                }
+                unsigned long long cand = __ballot(bnear);
+                while (cand) {
+                    const int bb = __builtin_amdgcn_readlane(bid, (int)__builtin_ctzll(cand));
+                    cand &= cand - 1ull;
+                    scan_bucket(bb);
+                }
             }
-        } else if (hit) {
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// <= 64 hits in `hits`: order them by original index (rank = number of smaller indices; they are distinct) and write
+// "the first nsample in index order, padded with the first" (ball_query_gpu.cu:29-43); an empty ball is all zeros
+__device__ __forceinline__ void bq_emit_list(int lane, const int *hits, int cnt, int nsample, int *__restrict__ out) {
+    __builtin_amdgcn_wave_barrier();
+    const int mine = lane < cnt ? hits[lane] : 0x7fffffff;
+    int rank = 0;
+    for (int j = 0; j < cnt; ++j) rank += __builtin_amdgcn_readlane(mine, j) < mine ? 1 : 0;
+    if (lane < cnt && rank < nsample) out[rank] = mine;
+    int first = 0;
+    if (cnt) first = __builtin_amdgcn_readlane(mine, (int)__builtin_ctzll(__ballot(lane < cnt && rank == 0)));
+    for (int l = cnt + lane; l < nsample; l += 64) out[l] = first;
+}
+
+// a crowded ball: every hit sets bit `original index` of an N-bit bitmap, which is then read back in order
+template <int DPL>
+__device__ __forceinline__ void bq_bitmap_search(int lane, int np, float r2, int nsample, float cx, float cy, float cz,
+                                                 const float4 *__restrict__ sorted, const float *__restrict__ boxes,
+                                                 const float *__restrict__ qboxes, int *__restrict__ out, unsigned *bits,
+                                                 int *quads) {
+#pragma unroll
+    for (int w = 0; w < DPL; ++w) bits[lane * DPL + w] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    bq_walk<DPL>(lane, np, r2, cx, cy, cz, sorted, boxes, qboxes, quads, [&](const float4 &p, float d2) {
+        if (d2 < r2) {
             const int k = __float_as_int(p.w);
             atomicOr(&bits[k >> 5], 1u << (k & 31));
         }
-    };
-    for (;;) {
-        cnt = 0;
-        if constexpr (DPL <= 2) {  // <= 64 buckets: one round over the bucket boxes, no second level
-            const bool bnear = lane < (np >> 6) && box_near(boxes + lane * 6, cx, cy, cz, radius2);
-            unsigned long long cand = __ballot(bnear);
-            while (cand) {
-                const int bb = (int)__builtin_ctzll(cand);
-                cand &= cand - 1ull;
-                scan_bucket(bb);
-            }
-        } else {
-            for (int q0 = 0; q0 < nq; q0 += 64) {
-                const int qd = q0 + lane;
-                const bool qnear = qd < nq && box_near(qboxes + qd * 6, cx, cy, cz, radius2);
-                const unsigned long long qmask = __ballot(qnear);
-                if (!qmask) continue;
-                const int nqc = (int)__popcll(qmask);
-                if (qnear) quads[popc_below(qmask)] = qd;
-                __builtin_amdgcn_wave_barrier();
-                for (int s0 = 0; s0 < nqc; s0 += 16) {
-                    const int slot = s0 + (lane >> 2);
-                    int bid = 0;
-                    bool bnear = false;
-                    if (slot < nqc) {
-                        bid = quads[slot] * 4 + (lane & 3);
-                        bnear = box_near(boxes + bid * 6, cx, cy, cz, radius2);
-                    }
-                    unsigned long long cand = __ballot(bnear);
-                    while (cand) {
-                        const int bb = __builtin_amdgcn_readlane(bid, (int)__builtin_ctzll(cand));
-                        cand &= cand - 1ull;
-                        scan_bucket(bb);
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        if (bitmap || cnt <= 64) break;
-        bitmap = true;  // a crowded ball: second pass, every hit sets bit `original index`
-#pragma unroll
-        for (int w = 0; w < DPL; ++w) bits[lane * DPL + w] = 0u;
-        __builtin_amdgcn_wave_barrier();
-    }
-
-    if (!bitmap) {
-        // order the <= 64 hits by original index: rank = number of smaller indices (they are distinct)
-        __builtin_amdgcn_wave_barrier();
-        const int mine = lane < cnt ? hits[lane] : 0x7fffffff;
-        int rank = 0;
-        for (int j = 0; j < cnt; ++j) rank += __builtin_amdgcn_readlane(mine, j) < mine ? 1 : 0;
-        if (lane < cnt && rank < nsample) out[rank] = mine;
-        // padding with the first hit (ball_query_gpu.cu:35-39); an empty ball is all zeros
-        int first = 0;
-        if (cnt) first = __builtin_amdgcn_readlane(mine, (int)__builtin_ctzll(__ballot(lane < cnt && rank == 0)));
-        for (int l = cnt + lane; l < nsample; l += 64) out[l] = first;
-        return;
-    }
-    // read the bitmap back in index order: lane l owns bits [l*32*DPL, (l+1)*32*DPL)
+    });
+    __builtin_amdgcn_wave_barrier();
+    // lane l owns bits [l*32*DPL, (l+1)*32*DPL)
     int bc = 0;
 #pragma unroll 8
     for (int i = 0; i < DPL; ++i) bc += __popc(bits[lane * DPL + i]);
@@ -348,6 +328,61 @@ __global__ __launch_bounds__(kQThreads) void bq_query_kernel(int np, int m, floa
     int first = 0;
     if (have) first = __builtin_amdgcn_readlane(mine_first, (int)__builtin_ctzll(have));
     for (int l = total + lane; l < nsample; l += 64) out[l] = first;
+}
+
+template <int K>
+struct BqScales {
+    float r2[K];   // radius * radius (ball_query_gpu.cu:23)
+    int nsample[K];
+    int *idx[K];   // (B, M, nsample[k])
+};
+
+template <int DPL, int K>
+__global__ __launch_bounds__(kQThreads) void bq_query_kernel(int np, int m, BqScales<K> sc,
+                                                             const float *__restrict__ new_xyz,
+                                                             const float4 *__restrict__ sorted,
+                                                             const float *__restrict__ boxes,
+                                                             const float *__restrict__ qboxes) {
+    __shared__ unsigned s_bits[kQThreads / 64][64 * DPL];
+    __shared__ int s_quads[kQThreads / 64][64];
+    __shared__ int s_hits[kQThreads / 64][K][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bs = blockIdx.y;
+    const int ci = blockIdx.x * (kQThreads / 64) + wave;
+    if (ci >= m) return;  // wave-uniform; no block-level barrier below
+    sorted += (size_t)bs * np;
+    boxes += (size_t)bs * (np / 64) * 6;
+    qboxes += (size_t)bs * (np / 256) * 6;
+    const float *c = new_xyz + ((size_t)bs * m + ci) * 3;
+    const float cx = c[0], cy = c[1], cz = c[2];
+    float r2max = sc.r2[0];
+#pragma unroll
+    for (int k = 1; k < K; ++k) r2max = fmaxf(r2max, sc.r2[k]);
+    int cnt[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) cnt[k] = 0;
+    bq_walk<DPL>(lane, np, r2max, cx, cy, cz, sorted, boxes, qboxes, s_quads[wave], [&](const float4 &p, float d2) {
+        if (!__ballot(d2 < r2max)) return;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const bool hit = d2 < sc.r2[k];
+            const unsigned long long hm = __ballot(hit);
+            if (hm) {
+                const int pos = cnt[k] + popc_below(hm);
+                if (hit && pos < 64) s_hits[wave][k][pos] = __float_as_int(p.w);
+                cnt[k] += (int)__popcll(hm);
+            }
+        }
+    });
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        int *out = sc.idx[k] + ((size_t)bs * m + ci) * sc.nsample[k];
+        if (cnt[k] <= 64)
+            bq_emit_list(lane, s_hits[wave][k], cnt[k], sc.nsample[k], out);
+        else
+            bq_bitmap_search<DPL>(lane, np, sc.r2[k], sc.nsample[k], cx, cy, cz, sorted, boxes, qboxes, out, s_bits[wave],
+                                  s_quads[wave]);
+    }
 }
 
 }  // namespace epnet
@@ -385,20 +420,22 @@ int epnet::spatial_index_launch(int b, int n, int np, const float *xyz, float4 *
     return check_launch("spatial index");
 }
 
-static int bq_query_launch(int b, int np, int m, float radius, int nsample, const float *new_xyz, const float4 *sorted,
-                           int *idx, hipStream_t s) {
+template <int K>
+static int bq_query_launch(int b, int np, int m, const BqScales<K> &sc, const float *new_xyz, const float4 *sorted,
+                           hipStream_t s) {
     const float *boxes = (const float *)(sorted + (size_t)b * np);
     const float *qboxes = boxes + (size_t)b * (np / 64) * 6;
-    const float radius2 = radius * radius;  // ball_query_gpu.cu:23
     dim3 grid(div_up(m, kQThreads / 64), b);
+#define EPNET_BQ(D_) hipLaunchKernelGGL((bq_query_kernel<D_, K>), grid, dim3(kQThreads), 0, s, np, m, sc, new_xyz, sorted, boxes, qboxes)
     switch (np / 2048) {
-        case 1: hipLaunchKernelGGL(bq_query_kernel<1>, grid, dim3(kQThreads), 0, s, np, m, radius2, nsample, new_xyz, sorted, boxes, qboxes, idx); break;
-        case 2: hipLaunchKernelGGL(bq_query_kernel<2>, grid, dim3(kQThreads), 0, s, np, m, radius2, nsample, new_xyz, sorted, boxes, qboxes, idx); break;
-        case 4: hipLaunchKernelGGL(bq_query_kernel<4>, grid, dim3(kQThreads), 0, s, np, m, radius2, nsample, new_xyz, sorted, boxes, qboxes, idx); break;
-        case 8: hipLaunchKernelGGL(bq_query_kernel<8>, grid, dim3(kQThreads), 0, s, np, m, radius2, nsample, new_xyz, sorted, boxes, qboxes, idx); break;
-        case 16: hipLaunchKernelGGL(bq_query_kernel<16>, grid, dim3(kQThreads), 0, s, np, m, radius2, nsample, new_xyz, sorted, boxes, qboxes, idx); break;
-        default: hipLaunchKernelGGL(bq_query_kernel<32>, grid, dim3(kQThreads), 0, s, np, m, radius2, nsample, new_xyz, sorted, boxes, qboxes, idx); break;
+        case 1: EPNET_BQ(1); break;
+        case 2: EPNET_BQ(2); break;
+        case 4: EPNET_BQ(4); break;
+        case 8: EPNET_BQ(8); break;
+        case 16: EPNET_BQ(16); break;
+        default: EPNET_BQ(32); break;
     }
+#undef EPNET_BQ
     return check_launch("ball_query query");
 }
 
@@ -427,7 +464,38 @@ extern "C" int epnet_ball_query_indexed(int b, int n, int m, float radius, int n
     if (index_bytes < need) return EPNET_ENOMEM;
     EPNET_REQUIRE(b <= 65535);
     const int np = scene_index_np(n);
-    return bq_query_launch(b, np, m, radius, nsample, new_xyz, (const float4 *)index, idx, (hipStream_t)stream);
+    BqScales<1> sc;
+    sc.r2[0] = radius * radius;  // ball_query_gpu.cu:23
+    sc.nsample[0] = nsample;
+    sc.idx[0] = idx;
+    return bq_query_launch<1>(b, np, m, sc, new_xyz, (const float4 *)index, (hipStream_t)stream);
+}
+
+// the nscales ball queries of an MSG level (same centres, same points) in one launch: boxes are tested against the
+// largest radius and every distance is computed once. idx[k]: (b, m, nsample[k]). Same results as nscales calls.
+extern "C" int epnet_ball_query_indexed_multi(int b, int n, int m, int nscales, const float *radii, const int *nsamples,
+                                              const float *new_xyz, const float *xyz, const void *index,
+                                              size_t index_bytes, int *const *idx, epnet_stream_t stream) {
+    EPNET_REQUIRE(nscales >= 0 && (nscales == 0 || (radii && nsamples && idx)));
+    const size_t need = scene_index_bytes(b, n);
+    bool fused = nscales == 2 && need != 0 && index && m > 0 && nsamples[0] > 0 && nsamples[1] > 0;
+    if (!fused) {
+        for (int k = 0; k < nscales; ++k) {
+            const int rc = epnet_ball_query_indexed(b, n, m, radii[k], nsamples[k], new_xyz, xyz, index, index_bytes, idx[k], stream);
+            if (rc) return rc;
+        }
+        return EPNET_OK;
+    }
+    EPNET_REQUIRE(new_xyz && idx[0] && idx[1]);
+    if (index_bytes < need) return EPNET_ENOMEM;
+    EPNET_REQUIRE(b <= 65535);
+    BqScales<2> sc;
+    for (int k = 0; k < 2; ++k) {
+        sc.r2[k] = radii[k] * radii[k];  // ball_query_gpu.cu:23
+        sc.nsample[k] = nsamples[k];
+        sc.idx[k] = idx[k];
+    }
+    return bq_query_launch<2>(b, scene_index_np(n), m, sc, new_xyz, (const float4 *)index, (hipStream_t)stream);
 }
 
 extern "C" size_t epnet_ball_query_workspace_bytes(int b, int n, int m) {

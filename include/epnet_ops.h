@@ -169,6 +169,12 @@ int epnet_three_nn_indexed(int b, int n, int m, const float *unknown, const floa
 /* same contract as epnet_ball_query (ball_query_gpu.cu:48-66) */
 int epnet_ball_query_indexed(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
                              const void *index, size_t index_bytes, int *idx, epnet_stream_t stream);
+/* the nscales ball queries of an MSG level (same centres, same points, nested balls) in ONE launch: every distance is
+ * computed once. radii / nsamples / idx are HOST arrays of nscales entries, idx[k] a device (b, m, nsamples[k])
+ * buffer. Same results as nscales calls of epnet_ball_query_indexed (which is what happens unless nscales == 2). */
+int epnet_ball_query_indexed_multi(int b, int n, int m, int nscales, const float *radii, const int *nsamples,
+                                   const float *new_xyz, const float *xyz, const void *index, size_t index_bytes,
+                                   int *const *idx, epnet_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------
  * iou3d (lib/utils/iou3d/src/iou3d.cpp:174-179); boxes are (N,5) [x1,y1,x2,y2,ry] f32

@@ -1,6 +1,6 @@
 /* TEST INFRASTRUCTURE: drives every function of the CPU oracle over small random and degenerate inputs.
- * Built by `make -C oracle sanitize` with -fsanitize=address,undefined (GPU sanitizers are not available on the
- * pool, so the CPU restatement -- the thing every GPU result is compared with -- is the code that gets them). */
+ * Built and run under the address / undefined-behaviour sanitizers by tests/test_sanitizers.py (GPU sanitizers are
+ * not available on the pool, so the CPU restatement -- what every GPU result is compared with -- gets them). */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>

@@ -166,6 +166,24 @@ def test_fps_over_scene_index_ties(oracle):
         np.testing.assert_array_equal(host(idx), oracle.furthest_point_sampling(xyz, m))
 
 
+@pytest.mark.parametrize("b,n,m,scales,kind", [
+    (2, 16384, 4096, ((0.1, 16), (0.5, 32)), "kitti"), (2, 4096, 1024, ((0.5, 16), (1.0, 32)), "kitti"),
+    (2, 1024, 256, ((1.0, 16), (2.0, 32)), "kitti"), (1, 16384, 700, ((2.5, 64), (0.3, 8)), "kitti"),  # crowded + unsorted radii
+    (2, 3000, 500, ((0.7, 5), (0.7, 9)), "ubox"), (1, 2048, 300, ((100.0, 40), (0.01, 3)), "dup"),
+    (2, 4096, 128, ((0.5, 16), (1.0, 32), (2.0, 8)), "kitti"),   # three scales: one launch per scale
+    (2, 500, 100, ((0.8, 16), (1.6, 32)), "kitti"),              # below the indexed range
+])
+def test_ball_queries_of_an_msg_level_in_one_launch(oracle, b, n, m, scales, kind):
+    from epnet_amd import pointnet2_cuda as ext
+    xyz = rand_cloud(b, n, seed=700 + n, kind=kind)
+    centres = np.ascontiguousarray(xyz[:, :: max(1, n // m)][:, :m])
+    d_xyz, d_c = dev(xyz), dev(centres)
+    outs = [torch.full((b, m, ns), -5, dtype=torch.int32, device=DEV) for _r, ns in scales]
+    ext.ball_query_multi_wrapper(b, n, m, [r for r, _ in scales], [ns for _, ns in scales], d_c, d_xyz, ext.scene_index(d_xyz), outs)
+    for (r, ns), got in zip(scales, outs):
+        np.testing.assert_array_equal(host(got), oracle.ball_query(r, ns, xyz, centres))
+
+
 def test_one_scene_index_serves_sampling_and_both_ball_queries(oracle):
     """the SA-level call pattern: index once, then FPS + the two MSG ball queries"""
     from epnet_amd import pointnet2_cuda as ext
