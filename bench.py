@@ -171,6 +171,10 @@ def op_family(name, head):
     if name.startswith("gather_points_w"):
         b, c, n, m = head[:4]
         return "gather", b * (m * 4 + c * n * 4 + c * m * 4)
+    if name.startswith("ball_query_multi"):  # all scales of the level in one launch: the bytes of each query
+        b, n, m, radii, nss = head[:5]
+        return ("ball_query N=%d M=%d r=%s ns=%s" % (n, m, "+".join("%g" % r for r in radii), "+".join(str(x) for x in nss)),
+                sum(b * (n * 12 + m * 12 + m * ns * 4) for ns in nss))
     if name.startswith("ball_query"):
         b, n, m, _r, ns = head[:5]
         return "ball_query N=%d M=%d r=%g ns=%d" % (n, m, _r, ns), b * (n * 12 + m * 12 + m * ns * 4)

@@ -48,9 +48,17 @@ class _PointnetSAModuleBase(nn.Module):
                 channels_first = xyz.transpose(1, 2).contiguous()
                 new_xyz = pointnet2_utils.gather_operation(channels_first, idx).transpose(1, 2).contiguous()
 
+        # the ball queries of all scales share one walk over the index (nested balls around the same centres)
+        idxs = None
+        if index is not None and len(self.groupers) > 1 and all(isinstance(g, pointnet2_utils.QueryAndGroup) for g in self.groupers):
+            idxs = pointnet2_utils.ball_query_multi([g.radius for g in self.groupers], [g.nsample for g in self.groupers],
+                                                    xyz, new_xyz.contiguous(), index)
         pooled = []
-        for grouper, mlp in zip(self.groupers, self.mlps):
-            grouped = grouper(xyz, new_xyz, features, index) if index is not None else grouper(xyz, new_xyz, features)
+        for k, (grouper, mlp) in enumerate(zip(self.groupers, self.mlps)):
+            if idxs is not None:
+                grouped = grouper(xyz, new_xyz, features, index, idxs[k])
+            else:
+                grouped = grouper(xyz, new_xyz, features, index) if index is not None else grouper(xyz, new_xyz, features)
             pooled.append(self._pool(mlp(grouped)).squeeze(-1))  # (B, mlp[-1], npoint)
         return new_xyz, torch.cat(pooled, dim=1), idx
 

@@ -220,6 +220,21 @@ class BallQuery(Function):
 ball_query = BallQuery.apply
 
 
+def ball_query_multi(radii, nsamples, xyz: torch.Tensor, new_xyz: torch.Tensor, index: Optional[torch.Tensor] = None):
+    """the ball queries of all scales of an MSG level (same centres, same points) in one launch: a list of
+    (B,npoint,nsample_k) int32 tensors, each equal to ``ball_query(radii[k], nsamples[k], xyz, new_xyz)``"""
+    assert new_xyz.is_contiguous() and xyz.is_contiguous()
+    batch, n = xyz.shape[0], xyz.shape[1]
+    npoint = new_xyz.shape[1]
+    if index is None:
+        index = scene_index(xyz)
+    if index is None:
+        return [ball_query(r, ns, xyz, new_xyz) for r, ns in zip(radii, nsamples)]
+    idxs = [_new(xyz, (batch, npoint, ns), torch.int32, zero=True) for ns in nsamples]
+    _ext.ball_query_multi_wrapper(batch, n, npoint, list(radii), list(nsamples), new_xyz.detach(), xyz.detach(), index, idxs)
+    return idxs
+
+
 class _GroupConcat(Function):
     """fused tail of QueryAndGroup: [grouped xyz - centre ; grouped features] written once into one tensor
     (the reference composes two grouping ops, an in-place subtraction and a torch.cat copy)"""
@@ -256,8 +271,10 @@ class QueryAndGroup(nn.Module):
         self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
 
     def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: Optional[torch.Tensor] = None,
-                index: Optional[torch.Tensor] = None):
-        idx = ball_query(self.radius, self.nsample, xyz, new_xyz, index)
+                index: Optional[torch.Tensor] = None, idx: Optional[torch.Tensor] = None):
+        """index: optional scene_index(xyz); idx: optional precomputed ball_query result (ball_query_multi)"""
+        if idx is None:
+            idx = ball_query(self.radius, self.nsample, xyz, new_xyz, index)
         if features is None:
             assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
         coords_need_grad = torch.is_grad_enabled() and (xyz.requires_grad or new_xyz.requires_grad)

@@ -77,6 +77,7 @@ class SAStack:
         # uses it); under a HIP graph it was measured equal to the reference's op-by-op sequence, which stays the default
         self.fused_sampling = fused_sampling
         self.tail_scales = int(os.environ.get("EPNET_SA_TAIL_SCALES", "0"))
+        self.multi_query = bool(int(os.environ.get("EPNET_SA_MULTI_QUERY", "1")))  # both scales of a level in one launch
         self.side = None
         self.npoints, self.radii, self.nsamples, self.feat_channels = npoints, radii, nsamples, feat_channels
         self.with_fp, self.fp = with_fp, fp
@@ -167,9 +168,20 @@ class SAStack:
             if L["c"]:
                 ext.group_points_wrapper(b, L["c"], n, m, S["ns"], L["features"], S["idx"], S["grouped_feat"])
 
+    def _query_level(self, L, cur_xyz, parity):
+        """the ball queries of all scales of the level: one launch over the shared index"""
+        P = L["sets"][parity]
+        if P["index"] is not None and self.multi_query:
+            ext.ball_query_multi_wrapper(self.batch, L["n"], L["m"], [S["radius"] for S in L["scales"]],
+                                         [S["ns"] for S in L["scales"]], P["new_xyz"], cur_xyz, P["index"],
+                                         [S["idx"] for S in L["scales"]])
+        else:
+            for S in L["scales"]:
+                self._query_scale(L, S, cur_xyz, parity)
+
     def _group_level(self, L, cur_xyz, parity):
+        self._query_level(L, cur_xyz, parity)
         for S in L["scales"]:
-            self._query_scale(L, S, cur_xyz, parity)
             self._group_scale(L, S, cur_xyz, parity)
 
     def _side_stream(self, device):
@@ -219,14 +231,16 @@ class SAStack:
                 if k == 0:       # level 2 (indexed queries: few registers) then its gathers beside the level-1 FPS
                     self._group_level(L, cur, 1 - parity)
             for L, cur in deep[1:]:
-                for S in L["scales"]:
-                    self._query_scale(L, S, cur, 1 - parity)
+                self._query_level(L, cur, 1 - parity)
             for L, cur in deep[1:]:
                 for S in L["scales"]:
                     self._group_scale(L, S, cur, 1 - parity)
-            for S in first["scales"][self.tail_scales:]:
-                self._query_scale(first, S, prev_xyz, 1 - parity)
-                self._group_scale(first, S, prev_xyz, 1 - parity)
+            if self.tail_scales == 0:
+                self._group_level(first, prev_xyz, 1 - parity)
+            else:
+                for S in first["scales"][self.tail_scales:]:
+                    self._query_scale(first, S, prev_xyz, 1 - parity)
+                    self._group_scale(first, S, prev_xyz, 1 - parity)
             if self.with_fp:
                 self._run_fp(prev_xyz, 1 - parity)
         cur = xyz
