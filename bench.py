@@ -196,11 +196,11 @@ def op_family(name, head):
 
 # kernels behind each op family (rocprofv3 names), for the PMC lookup and for the reader of the JSON line
 FAMILY_KERNELS = {
-    "fps N=16384 M=4096": ["epnet::pruned::fps_indexed_kernel<8, 32>"],
-    "fps N=4096 M=1024": ["epnet::pruned::fps_indexed_kernel<4, 16>"],
+    "fps N=16384 M=4096": ["epnet::pruned::fps_indexed_kernel<8, 32, false>"],
+    "fps N=4096 M=1024": ["epnet::pruned::fps_indexed_kernel<4, 16, false>"],
     "group": ["epnet::group_xyz_centred_vec4_kernel", "epnet::gather_rows_lds_kernel"],
     "group_xyz": ["epnet::group_xyz_centred_vec4_kernel"],
-    "scene_index N=16384": ["epnet::bq_index_kernel"],
+    "scene_index N=16384": ["epnet::bq_index_kernel<1024, 14>"],
 }
 PMC_PROFILE = os.path.join("profiles", "r01_pmc_traffic.json")
 

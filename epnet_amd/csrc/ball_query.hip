@@ -115,11 +115,13 @@ __global__ __launch_bounds__(kBqThreads) void ball_query_kernel(int n, int m, fl
 //                    result: the first nsample hits in index order, padded with the first one.
 // The point test is the same expression as above: d2 = (cx-x)*(cx-x) + (cy-y)*(cy-y) + (cz-z)*(cz-z).
 
-constexpr int kIxThreads = 1024;
-
+// T threads, 2^BITS grid cells: <1024, 14> for big scenes; <256, 12> for n <= 4096, where 4096 cells are plenty and a
+// workgroup of 4 waves with 18 KB of LDS finds room on a CU that the wide kernels of the pipelined stack occupy
+template <int kIxThreads, int BITS>
 __global__ __launch_bounds__(kIxThreads) void bq_index_kernel(int n, int np, const float *__restrict__ xyz,
                                                               float4 *__restrict__ sorted, float *__restrict__ boxes,
                                                               float *__restrict__ qboxes) {
+    constexpr int kCells = 1 << BITS;
     extern __shared__ int s_hist[];  // cell histogram / running offsets (spatial.h)
     __shared__ float s_box[6][16];
     __shared__ int s_part[16];
@@ -129,12 +131,12 @@ __global__ __launch_bounds__(kIxThreads) void bq_index_kernel(int n, int np, con
     boxes += (size_t)blockIdx.x * (np / 64) * 6;
     float lo[3], ext[3];
     block_bbox3(xyz, n, s_box, lo, ext);
-    const CellGrid g = make_cell_grid(lo, ext);
+    const CellGrid g = make_cell_grid(lo, ext, BITS);
     // counting sort by cell, scattering the points (with their original index) straight to global memory
     constexpr int per = kCells / kIxThreads;
     constexpr int per_shift = per == 16 ? 4 : per == 8 ? 3 : per == 4 ? 2 : -1;
     static_assert(per_shift > 0, "scan layout");
-    for (int i = q; i < cell_hist_words(kIxThreads); i += kIxThreads) s_hist[i] = 0;
+    for (int i = q; i < kCells + kCells / per + 64; i += kIxThreads) s_hist[i] = 0;
     __syncthreads();
     for (int k = q; k < n; k += kIxThreads)
         atomicAdd(&s_hist[hist_at((int)cell_code(g, xyz[k * 3 + 0], xyz[k * 3 + 1], xyz[k * 3 + 2]), per_shift)], 1);
@@ -410,13 +412,20 @@ extern "C" int epnet_ball_query(int b, int n, int m, float radius, int nsample, 
     return check_launch("ball_query");
 }
 
-static size_t bq_index_lds(int) { return (size_t)(kCells + kCells / (kCells / kIxThreads) + 64) * sizeof(int); }
 
 // shared with three_nn (interpolate.hip): cell-sorted float4 copy (x, y, z, original index) of n points padded
 // to np (a multiple of 64) per scene, plus one box (6 floats) per 64 sorted points
 int epnet::spatial_index_launch(int b, int n, int np, const float *xyz, float4 *sorted, float *boxes, float *qboxes,
                                 hipStream_t s) {
-    hipLaunchKernelGGL(bq_index_kernel, dim3(b), dim3(kIxThreads), bq_index_lds(np), s, n, np, xyz, sorted, boxes, qboxes);
+    if (n <= 4096) {
+        constexpr int T = 256, cells = 1 << 12;
+        hipLaunchKernelGGL((bq_index_kernel<T, 12>), dim3(b), dim3(T), (size_t)(cells + cells / (cells / T) + 64) * sizeof(int), s, n,
+                           np, xyz, sorted, boxes, qboxes);
+    } else {
+        constexpr int T = 1024, cells = 1 << 14;
+        hipLaunchKernelGGL((bq_index_kernel<T, 14>), dim3(b), dim3(T), (size_t)(cells + cells / (cells / T) + 64) * sizeof(int), s, n,
+                           np, xyz, sorted, boxes, qboxes);
+    }
     return check_launch("spatial index");
 }
 

@@ -108,7 +108,7 @@ struct CellGrid {
     int bits[3];  // log2(cells) per axis
 };
 
-__device__ __forceinline__ CellGrid make_cell_grid(const float (&lo)[3], const float (&ext)[3]) {
+__device__ __forceinline__ CellGrid make_cell_grid(const float (&lo)[3], const float (&ext)[3], int max_bits = kCellBits) {
     CellGrid g;
     const float big = fmaxf(ext[0], fmaxf(ext[1], ext[2]));
     float cell = big > 0.f ? big / 64.f : 1.f;
@@ -122,7 +122,7 @@ __device__ __forceinline__ CellGrid make_cell_grid(const float (&lo)[3], const f
             g.bits[a] = b;
             total += b;
         }
-        if (total <= kCellBits) break;
+        if (total <= max_bits) break;
         cell *= 1.26f;  // ~ one bit less in total every 3 iterations
     }
     g.lo[0] = lo[0]; g.lo[1] = lo[1]; g.lo[2] = lo[2];

@@ -208,16 +208,19 @@ class SAStack:
         if self.with_fp:
             self._run_fp(xyz, 0)
 
-    def run_pipelined(self, xyz, prev_xyz, parity):
-        """one steady-state step: stage S of this batch (into set `parity`) beside stage G of the previous
-        batch (`prev_xyz`, whose stage S filled set 1 - parity in the step before). (Splitting stage G further,
-        ball queries beside groupings on a third stream, was measured: no gain eagerly, a loss under a graph.)"""
+    def run_pipelined(self, xyz, prev_xyz, step):
+        """one steady-state step: stage S of this batch (into set `step & 1`) beside stage G of the previous
+        batch (`prev_xyz`, whose stage S filled the other set in the step before). Measured dead ends: splitting
+        stage G further (ball queries beside groupings on a third stream) gains nothing eagerly and loses under a
+        graph; building the next batch's level-1 index one step early (three rotating buffers) only moves the
+        contention, the step stays stage-G bound."""
+        parity = step & 1
         main = torch.cuda.current_stream(xyz.device)
         side = self._side_stream(xyz.device)
-        # the level-1 scene index of this batch goes first: it is a one-workgroup-per-scene kernel that cannot
-        # find a free CU once the wide stage-G kernels are in flight
         first = self.levels[0]
         if first["sets"][parity]["index"] is not None:
+            # built before stage G is issued: a one-workgroup-per-scene kernel with 64 KB of LDS cannot find a free
+            # CU once the wide stage-G kernels are in flight
             ext.scene_index_build_wrapper(self.batch, first["n"], xyz, first["sets"][parity]["index"])
         side.wait_stream(main)
         with torch.cuda.stream(side):
@@ -270,9 +273,17 @@ class SAStack:
             weight = inv / torch.sum(inv, dim=2, keepdim=True)
             ext.three_interpolate_wrapper(b, F["c"], F["m"], F["n"], F["known_feats"], F["idx"], weight, F["out"])
 
+    def _prime(self, xyz):
+        """before the first pipelined step: stage S of `xyz` into BOTH sets, so that the first steps' stage G (the
+        "previous batch") reads valid centres and indices, never uninitialised memory"""
+        for parity in (0, 1):
+            cur = xyz
+            for L in self.levels:
+                cur = self._sample_level(L, cur, parity)
+
     def _step_eager(self, k):
         if self.pipelined:
-            self.run_pipelined(self.static_xyz, self.static_xyz, k & 1)
+            self.run_pipelined(self.static_xyz, self.static_xyz, k)
         else:
             self.run(self.static_xyz)
 
@@ -282,13 +293,19 @@ class SAStack:
         self.static_xyz = xyz.clone()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
+        period = 1
         with torch.cuda.stream(s):
-            for k in range(2):   # warm-up outside capture; fills both parities
+            if self.pipelined:
+                self._prime(self.static_xyz)
+        if self.pipelined:
+            period = 2   # one graph per parity
+        with torch.cuda.stream(s):
+            for k in range(max(2, period)):   # warm-up outside capture; fills every buffer of the rotation
                 self._step_eager(k)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self.graphs = []
-        for k in range(2 if self.pipelined else 1):
+        for k in range(period):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._step_eager(k)
@@ -307,7 +324,8 @@ class SAStack:
         if self.pipelined:
             if self.static_xyz is None:
                 self.static_xyz = xyz
-                self.run_pipelined(xyz, xyz, 1)  # prime the other parity
+                self._prime(xyz)
+                self.replays = 0
             self.run_pipelined(xyz, self.static_xyz, self.replays & 1)
             self.replays += 1
         else:

@@ -21,9 +21,10 @@ import re
 import statistics
 import sys
 
-FPS = {"fps_indexed_kernel<8, 32>": "fps N=16384 M=4096", "fps_indexed_kernel<4, 16>": "fps N=4096 M=1024",
-       "fps_pruned_kernel<8, 32>": "fps N=16384 M=4096", "fps_pruned_kernel<4, 16>": "fps N=4096 M=1024",
-       "fps_wave_kernel<1, 16>": "fps N=1024 M=256", "fps_wave_kernel<1, 4>": "fps N=256 M=64"}
+# kernel-name prefixes (template argument lists may continue) -> op family
+FPS = {"fps_indexed_kernel<8, 32": "fps N=16384 M=4096", "fps_indexed_kernel<4, 16": "fps N=4096 M=1024",
+       "fps_pruned_kernel<8, 32": "fps N=16384 M=4096", "fps_pruned_kernel<4, 16": "fps N=4096 M=1024",
+       "fps_wave_kernel<1, 16": "fps N=1024 M=256", "fps_wave_kernel<1, 4": "fps N=256 M=64"}
 
 
 def short(name):
@@ -53,7 +54,7 @@ def families(rows):
             elif "bq_index_kernel" in n:
                 fam = "scene_index"
             elif "bq_query_kernel" in n or "ball_query_kernel" in n:
-                fam = "ball_query " + re.search(r"(bq_query_kernel<\d+>|ball_query_kernel<\d+>)", n).group(1)
+                fam = "ball_query " + re.search(r"(bq_query_kernel<[\d, ]+>|ball_query_kernel<\d+>)", n).group(1)
             else:
                 fam = "torch: " + n[:60]
         out.append((fam, idx))

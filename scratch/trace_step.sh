@@ -9,7 +9,7 @@ f = glob.glob("gpurun_out/trace/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # find the timed steps: take the last 40% of FPS<8,32> launches from graph replays: just print a window around the 3rd-from-last big fps kernel
-fps = [i for i, r in enumerate(rows) if "fps_indexed_kernel<8, 32>" in r["Kernel_Name"] or "fps_pruned_kernel<8, 32>" in r["Kernel_Name"]]
+fps = [i for i, r in enumerate(rows) if "fps_indexed_kernel<8, 32" in r["Kernel_Name"] or "fps_pruned_kernel<8, 32" in r["Kernel_Name"]]
 print("fps L1 launches", len(fps))
 # steps: warmup eager 2 (capture warmup) + capture itself not executed + warmup 2 + steps 4 + instrumented 4
 k = fps[-6]   # a replay in the timed region (before the 4 instrumented eager steps)
