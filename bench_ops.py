@@ -76,7 +76,10 @@ def main():
     # ---- FP ops
     for bsz, (c, m, n) in ((16, (256, 4096, 16384)), (16, (512, 1024, 4096)), (1, (256, 4096, 16384))):
         unknown = synth.scenes("kitti", bsz, n, seed=7).to(dev)
-        known = unknown[:, :m].contiguous()
+        # as in an FP module: the known set is the FPS subset of the unknown one
+        kidx = torch.empty((bsz, m), dtype=i32, device=dev)
+        known = torch.empty((bsz, m, 3), device=dev)
+        p2.sample_centres_wrapper(bsz, n, m, unknown, p2.scene_index(unknown), kidx, known)
         d2 = torch.empty((bsz, n, 3), device=dev); idx = torch.empty((bsz, n, 3), dtype=i32, device=dev)
         ms = timeit(lambda: p2.three_nn_wrapper(bsz, n, m, unknown, known, d2, idx))
         report("three_nn", {"B": bsz, "n": n, "m": m}, ms, bsz * (n * 12 + m * 12 + n * 24), "builds its own index of the known set")
