@@ -260,6 +260,10 @@ __global__ __launch_bounds__(64 * W) void fps_wave_kernel(int n, int m, int lg_b
 // waves -- exactly the winner of the reference's strided scan + shared-memory tree.
 namespace pruned {
 
+#ifndef EPNET_FPS_PRIO
+#define EPNET_FPS_PRIO 3
+#endif
+
 #ifdef EPNET_FPS_STATS  // diagnostic build only (scratch/fps_stats.hip): phase cycle counters
 __device__ unsigned long long g_stats[16];
 #define EPNET_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
@@ -396,7 +400,7 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
 
     // a strictly serial chain: when it shares a SIMD with a wide kernel (software-pipelined SA stack), every
     // instruction it has ready should issue first
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(EPNET_FPS_PRIO);
     EPNET_STATS_BEGIN;
     EPNET_STAMP(t_loop0);
     // this wave's best point, recomputed only in rounds that changed one of its buckets
@@ -722,7 +726,7 @@ __global__ __launch_bounds__(kBigThreads) void fps_bigscene_kernel(int n, int np
     float cx = xyz[0], cy = xyz[1], cz = xyz[2];
     __syncthreads();
 
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(EPNET_FPS_PRIO);
     bool stale = true;
     int wbest = kNeg1;
     bool publisher = false;
@@ -928,6 +932,9 @@ extern "C" int epnet_furthest_point_sampling(int b, int n, int m, const float *x
                 waves = w;
                 break;
             }
+        // few scenes of 512 < n <= 1024 points: the chip is idle anyway and a round is shorter with 2 slots per
+        // thread on 8 waves (0.48 us) than with 16 slots on one wave (0.66 us); many small scenes pack best at 1 wave
+        if (n > 512 && b <= 512 && bs_ref / 64 >= 8 && waves < 8) waves = 8;
         if (const char *e = getenv("EPNET_FPS_WAVES")) {
             const int w = atoi(e);
             if (w >= 1 && w <= bs_ref / 64 && (w & (w - 1)) == 0 && (bs_ref / (64 * w)) * J <= 16) waves = w;
