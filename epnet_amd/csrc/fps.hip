@@ -355,10 +355,10 @@ __device__ __forceinline__ void set_rank(VH &rk2, int j, unsigned r) {  // j is 
 // A slot is split into 64/PPT parts of PPT lanes: these parts are the pruning buckets, and bucket
 // (slot j, part p) is summarised in lane p*PPT + j -- a lane of the part itself, so a part's maximum
 // reaches its summary lane with an in-row DPP reduction and a lane-id compare, no cross-lane move.
-// Cross-wave arg-max: every wave's best point enters ONE 64-bit LDS atomic max on the key
-// (distance bits << 32 | (0x3FFF - rank) << 4 | wave): the larger distance wins, equal distances go to the
+// Cross-wave arg-max: every thread holding its wave's maximum enters ONE 64-bit LDS atomic max on the key
+// (distance bits << 32 | (0x3FFF - rank) << 10 | thread): the larger distance wins, equal distances go to the
 // smaller reference rank -- and after the round's single barrier the winner is read back with two
-// dependent LDS loads (key, then that wave's coordinates), no cross-lane reduction at all.
+// dependent LDS loads (key, then that thread's coordinates), no cross-lane reduction at all.
 // kCtr: also emit the selected points' coordinates (ctr, m x 3 floats): the gather that follows the sampling
 // in an SA module (pointnet2_modules.py:39-45) comes for free, the round's winner is in registers anyway.
 template <int kW, int PPT, bool kCtr, typename VF, typename VI, typename VH>
@@ -366,7 +366,7 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
                                            float cx, float cy, float cz, int *__restrict__ idxs,
                                            float *__restrict__ ctr) {
     __shared__ unsigned long long s_key[3];
-    __shared__ float4 s_rec[2][16];
+    __shared__ float4 s_rec[2][64 * kW];  // one record slot per thread
     __shared__ int s_idx[kIdxBufP];
     __shared__ float s_ctr[kCtr ? kIdxBufP * 3 : 1];
     const int q = threadIdx.x;
@@ -435,13 +435,14 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
             bm = (sub == j) ? gm : bm;
         }
         EPNET_STAMP(t2);
-        // C. this wave's maximum; the points that hold it (usually exactly one) compete by reference rank
+        // C. this wave's maximum. EVERY lane holding it (usually exactly one) publishes its point: its own record
+        // slot and the atomic key, which orders equal distances by reference rank -- no holder count, no second
+        // reduction, whatever the number of ties
         if (stale) {
             stale = false;
             wbest = wave_max_all(bm);
             unsigned cand = fold_parts<PPT>(__ballot(bm == wbest));
             racc = 0xFFFFFFFFu;
-            int holders = 0;
             do {
                 const int j = (int)__builtin_ctz(cand);
                 cand &= cand - 1u;
@@ -449,41 +450,35 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
                 const float xj = x[j], yj = y[j], zj = z[j];
                 const unsigned rw = (unsigned)rk2[j >> 1];
                 __builtin_amdgcn_sched_barrier(0);  // one GPR-index window for the four slot registers
-                const bool eq = tj == wbest;
-                holders += (int)__popcll(__ballot(eq));
-                const unsigned r = eq ? ((rw >> ((j & 1) << 4)) & 0xFFFFu) : 0xFFFFFFFFu;
-                const bool take = r < racc;
+                const unsigned r = tj == wbest ? ((rw >> ((j & 1) << 4)) & 0xFFFFu) : 0xFFFFFFFFu;
+                const bool take = r < racc;  // a lane holding the maximum in two of its slots keeps the smaller rank
                 racc = take ? r : racc;
                 xa = take ? xj : xa;
                 ya = take ? yj : ya;
                 za = take ? zj : za;
             } while (cand);
-            if (holders != 1) {  // several equal maxima in this wave: only the smallest rank stays a publisher
-                const unsigned rmin = wave_min_all(racc);
-                racc = racc == rmin ? racc : 0xFFFFFFFFu;
-            }
             if (wbest == kNeg1) racc = 0xFFFFFFFFu;  // a wave of padding only
         }
         const int buf = it & 1;
         if (racc != 0xFFFFFFFFu) {
-            s_rec[buf][wave] = make_float4(xa, ya, za, 0.f);
+            s_rec[buf][q] = make_float4(xa, ya, za, 0.f);
             const unsigned long long key =
-                ((unsigned long long)(unsigned)wbest << 32) | (unsigned long long)(((0x3FFFu - racc) << 4) | (unsigned)wave);
+                ((unsigned long long)(unsigned)wbest << 32) | (unsigned long long)(((0x3FFFu - racc) << 10) | (unsigned)q);
             __hip_atomic_fetch_max(&s_key[kb], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         EPNET_STAMP(t3);
         __syncthreads();
         EPNET_STAMP(t4);
-        // D. the winner: key, then its wave's coordinates (both loads are wave-uniform broadcasts)
+        // D. the winner: key, then its thread's coordinates (both loads are wave-uniform broadcasts)
         const unsigned klo = (unsigned)s_key[kb];
-        const float4 rec = s_rec[buf][klo & 15u];
+        const float4 rec = s_rec[buf][klo & 1023u];
         cx = rec.x;
         cy = rec.y;
         cz = rec.z;
         const int kb2 = kb == 0 ? 2 : kb - 1;  // == (it + 2) % 3: last read in round it-1, next used in round it+2
         kb = kb == 2 ? 0 : kb + 1;
         if (wave == 0) {
-            s_idx[it & (kIdxBufP - 1)] = (int)(0x3FFFu - (klo >> 4));  // all lanes, same word; converted at the flush
+            s_idx[it & (kIdxBufP - 1)] = (int)(0x3FFFu - (klo >> 10));  // all lanes, same word; converted at the flush
             if (lane == 0) s_key[kb2] = 0ull;
             if (kCtr && lane < 3) s_ctr[(it & (kIdxBufP - 1)) * 3 + lane] = lane == 0 ? cx : (lane == 1 ? cy : cz);
             if ((it & (kIdxBufP - 1)) == kIdxBufP - 1) {
