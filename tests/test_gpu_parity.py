@@ -389,10 +389,11 @@ def test_three_nn_indexed_and_direct_paths_agree(oracle):
     (2, 700, 1100, "kitti"),      # unknown set below the indexed range: known-index-only kernel
     (2, 3000, 300, "kitti"),      # known set below it: plain path
 ])
-def test_three_nn_over_scene_indices_matches_oracle(oracle, b, n, m, kind):
+def test_three_nn_over_scene_indices_matches_oracle(oracle, b, n, m, kind, monkeypatch):
     """epnet_three_nn_indexed with both point sets indexed (one wave per unknown bucket), with the known set only,
     and with neither: indices and squared distances bit-equal to the oracle"""
     from epnet_amd import pointnet2_cuda as ext
+    monkeypatch.setenv("EPNET_NN_TILE_MIN_BUCKETS", "1")   # the library keeps the bucket kernel for big launches only
     unknown = rand_cloud(b, n, seed=n + 1, kind=kind)
     known = rand_cloud(b, m, seed=m + 2, kind=kind)
     if kind == "dup":
