@@ -2,17 +2,16 @@
 //
 // Replaces furthest_point_sampling_kernel / _launcher of the reference
 // (pointnet2_lib/pointnet2/src/sampling_gpu.cu:94-253). One workgroup per scene, as there, but the
-// M-1 dependent arg-max iterations are rebuilt around the CDNA4 execution model:
+// M-1 dependent arg-max iterations are rebuilt around the CDNA4 execution model. Four kernels:
 //
-//   * the scene lives in VGPRs for the whole kernel (x, y, z and the running min distance of up
-//     to 16 points per thread): HBM sees N*12 B once and M*4 B of indices; the reference re-reads
-//     xyz and temp from memory in every iteration;
-//   * NO global memory access inside the loop: the coordinates of each wave's candidate travel
-//     with its maximum through a 16-entry LDS exchange, and the selected indices are buffered in
-//     LDS and flushed with coalesced stores -- so the single barrier per iteration never waits on
-//     vmcnt (the reference has 11 barriers and a dependent global load per iteration);
-//   * wave-level arg-max = one DPP max-reduction of the float + __ballot + s_ff1 (no LDS
-//     butterfly), because tie-breaking is folded into the lane layout, see below.
+//   fps_wave_kernel      N <= 1024 (and the brute-force fallback): the scene lives in VGPRs; lane / slot order
+//                        equals the reference's tie-break order, so the wave arg-max is a DPP max + ballot + ff1;
+//   pruned::fps_*_kernel 1024 < N <= 16384: registers again, points in spatial order, exact bucket pruning
+//                        (see "pruned kernel" below) -- over a caller-built scene index or self-sorting;
+//   fps_bigscene_kernel  16384 < N <= 65536: bucket summaries in registers, points re-read from the index;
+//   fps_stream_kernel    anything else: xyz / temp re-read through L2.
+// Common to all but the last: NO global memory access inside the round loop (the selected indices are buffered in
+// LDS and flushed with coalesced stores), one barrier per round (the reference has 11 and a dependent global load).
 //
 // Tie-breaking. The reference's result depends on its block size bs = opt_n_threads(N)
 // (cuda_utils.h:10-14): thread tid scans k = tid, tid+bs, ... keeping the FIRST maximum (strict
@@ -237,17 +236,18 @@ __global__ __launch_bounds__(64 * W) void fps_wave_kernel(int n, int m, int lg_b
 
 // ---- pruned kernel ------------------------------------------------------------------------------
 //
-// Exact FPS with spatial pruning, for 1024 < N <= 16384. The points are sorted by grid cell
-// (in-kernel counting sort on an interleaved cell code, spatial.h) and dealt to "buckets" of 64 consecutive sorted points: bucket b is
-// slot b/W of wave b%W, one point per lane. A wave keeps, for each of its buckets j, a summary in LANE j
-// of a few registers (bounding box, maximum running distance bm, reference rank of the point holding
-// it) plus that point's coordinates in a small LDS table. A new sample c can only lower distances in
-// buckets whose box lies closer than their bm, so per round a wave
-//   A. evaluates L_j = |clamp(c, box_j) - c|^2 for all its buckets at once (one bucket per lane),
-//   B. updates only the buckets with L_j < bm_j (typically 0-3 of them; the slot registers are
-//      addressed with the gfx9 GPR-index mode, so there is one copy of the code and no branch tree),
-//   C. reduces its bucket maxima and publishes (value, coordinates, rank) of its best point,
-//   D. after the single barrier picks the best wave's record.
+// Exact FPS with spatial pruning, for 1024 < N <= 16384. The points are sorted by grid cell (a scene index
+// built beforehand, or an in-kernel counting sort on an interleaved cell code, spatial.h) and dealt in groups of
+// 64 consecutive sorted points to (wave, slot) registers: group g is slot g/W of wave g%W, one point per lane.
+// Every slot is split into 64/PPT buckets of PPT lanes; a bucket's summary (bounding box, maximum running
+// distance bm) lives in one lane of the bucket itself. A new sample c can only lower distances in buckets whose
+// box lies closer than their bm, so per round a wave
+//   A. evaluates L = |clamp(c, box) - c|^2 for all its 64 buckets at once (one bucket per lane),
+//   B. updates only the slots holding a bucket with L < bm (typically 0-3; the slot registers are addressed
+//      with the gfx9 GPR-index mode, so there is one copy of the code and no branch tree),
+//   C. reduces its bucket maxima; every thread holding the wave's maximum publishes its point (coordinates
+//      into its record slot, (distance, rank, thread) into one 64-bit LDS atomic max),
+//   D. after the single barrier reads the winning key and that thread's coordinates.
 // Everything after the `active` mask stays on the vector ALU (DPP / permlane-swap reductions, lane
 // masks instead of readlane -> SALU -> VALU round trips).
 // Skipping is EXACT, not approximate: L_j is computed with the very expression used for point
