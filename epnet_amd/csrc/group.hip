@@ -233,9 +233,11 @@ static int launch_gather_rows(int b, int c, int n, long long p, const float *poi
 constexpr int kCsrThreads = 1024;
 constexpr int kCsrMaxTargets = 16384;
 
-// offsets: (n+1) ints, perm: p ints, per scene
+// offsets: (n+1) ints, perm: p ints, per scene. The key of position t is idx[t], or with key_div > 0
+// idx[t] + (t / key_div) * key_mul (positions partitioned into runs of key_div, each run with its own key range).
 __global__ __launch_bounds__(kCsrThreads) void csr_build_kernel(int n, int p, const int *__restrict__ idx,
-                                                                int *__restrict__ offsets, int *__restrict__ perm) {
+                                                                int *__restrict__ offsets, int *__restrict__ perm,
+                                                                int key_div, int key_mul) {
     extern __shared__ int s_hist[];
     __shared__ int s_part[16];
     const int q = threadIdx.x, lane = q & 63, wave = q >> 6;
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(kCsrThreads) void csr_build_kernel(int n, int p, co
     __syncthreads();
     // bin j lives at j + j / per: thread-contiguous runs fall on distinct banks
     for (int t = q; t < p; t += kCsrThreads) {
-        const int j = idx[t];
+        const int j = idx[t] + (key_div ? (t / key_div) * key_mul : 0);
         atomicAdd(&s_hist[j + j / per], 1);
     }
     __syncthreads();
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(kCsrThreads) void csr_build_kernel(int n, int p, co
     if (q == kCsrThreads - 1) offsets[n] = p;
     __syncthreads();
     for (int t = q; t < p; t += kCsrThreads) {
-        const int j = idx[t];
+        const int j = idx[t] + (key_div ? (t / key_div) * key_mul : 0);
         perm[atomicAdd(&s_hist[j + j / per], 1)] = t;
     }
 }
@@ -315,10 +317,10 @@ __global__ __launch_bounds__(kCsrThreads) void scatter_rows_csr_kernel(int c, in
     }
 }
 
-int csr_build_launch(int b, int n, int p, const int *idx, int *offsets, int *perm, hipStream_t s) {
+int csr_build_launch(int b, int n, int p, const int *idx, int *offsets, int *perm, hipStream_t s, int key_div, int key_mul) {
     const int per = (n + kCsrThreads - 1) / kCsrThreads;
     hipLaunchKernelGGL(csr_build_kernel, dim3(b), dim3(kCsrThreads), (size_t)kCsrThreads * (per + 1) * sizeof(int), s, n, p, idx,
-                       offsets, perm);
+                       offsets, perm, key_div, key_mul);
     return check_launch("csr_build");
 }
 

@@ -484,48 +484,70 @@ __global__ __launch_bounds__(kTiThreads) void three_interpolate_grad_lds_kernel(
 // atomic-free gradient (see scatter_rows_csr_kernel in group.hip): the 3n (unknown, slot) pairs are grouped by
 // their known point; a workgroup stages ROWS rows of grad_out in LDS and every known point j sums
 // w * grad_out over its own list.
+// The unknowns are cut into `parts` runs of part_len: a workgroup stages ROWS rows of ONE run at a time (so 8 rows fit
+// LDS even at n = 16384), the inverse index is keyed by (run, known point), and a thread carries its partial sums
+// across the runs -- the index is read once per 8 rows instead of once per 2.
 constexpr int kTigThreads = 1024;
+constexpr int kTigMaxTargets = 4;  // known points per thread: m <= 4096 per pass
 template <int ROWS>
-__global__ __launch_bounds__(kTigThreads) void three_interpolate_grad_csr_kernel(int c, int n, int m,
+__global__ __launch_bounds__(kTigThreads) void three_interpolate_grad_csr_kernel(int c, int n, int m, int parts, int part_len,
                                                                                const float *__restrict__ grad_out,
                                                                                const float *__restrict__ weight,
                                                                                const int *__restrict__ offsets,
                                                                                const int *__restrict__ perm,
                                                                                float *__restrict__ grad_points) {
-    extern __shared__ float s_go[];  // ROWS * n floats
+    extern __shared__ float s_go[];  // ROWS * part_len floats
     const int bs = blockIdx.y;
     const int c0 = blockIdx.x * ROWS;
     const int nr = min(ROWS, c - c0);
     const float *go = grad_out + ((size_t)bs * c + c0) * n;
-    const int total = nr * n;
-    if ((n & 3) == 0 && ((uintptr_t)go & 15) == 0) {
-        const float4 *src4 = reinterpret_cast<const float4 *>(go);
-        float4 *dst4 = reinterpret_cast<float4 *>(s_go);
-        for (int e = threadIdx.x; e < total / 4; e += kTigThreads) dst4[e] = src4[e];
-    } else {
-        for (int e = threadIdx.x; e < total; e += kTigThreads) s_go[e] = go[e];
-    }
-    __syncthreads();
-    offsets += (size_t)bs * (m + 1);
+    offsets += (size_t)bs * ((size_t)parts * m + 1);
     perm += (size_t)bs * n * 3;
     weight += (size_t)bs * n * 3;
     float *gp = grad_points + ((size_t)bs * c + c0) * m;
-    for (int j = threadIdx.x; j < m; j += kTigThreads) {
-        const int beg = offsets[j], end = offsets[j + 1];
-        float acc[ROWS];
+    for (int j0 = 0; j0 < m; j0 += kTigThreads * kTigMaxTargets) {  // one pass for m <= 4096
+        float acc[kTigMaxTargets][ROWS];
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
-        for (int t = beg; t < end; ++t) {
-            const int q = perm[t];  // = unknown * 3 + slot
-            const int i = q / 3;
-            const float w = weight[q];
+        for (int u = 0; u < kTigMaxTargets; ++u)
 #pragma unroll
-            for (int r = 0; r < ROWS; ++r)
-                if (r < nr) acc[r] += s_go[r * n + i] * w;
+            for (int r = 0; r < ROWS; ++r) acc[u][r] = 0.f;
+        for (int part = 0; part < parts; ++part) {
+            const int i0 = part * part_len, len = min(part_len, n - i0);
+            __syncthreads();  // the previous run is no longer being read
+            for (int r = 0; r < nr; ++r) {
+                const float *src = go + (size_t)r * n + i0;
+                float *dst = s_go + r * part_len;
+                if ((len & 3) == 0 && ((uintptr_t)src & 15) == 0) {
+                    for (int e = threadIdx.x; e < len / 4; e += kTigThreads)
+                        reinterpret_cast<float4 *>(dst)[e] = reinterpret_cast<const float4 *>(src)[e];
+                } else {
+                    for (int e = threadIdx.x; e < len; e += kTigThreads) dst[e] = src[e];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < kTigMaxTargets; ++u) {
+                const int j = j0 + u * kTigThreads + threadIdx.x;
+                if (j >= m) continue;
+                const int beg = offsets[part * m + j], end = offsets[part * m + j + 1];
+                for (int t = beg; t < end; ++t) {
+                    const int q = perm[t];  // = unknown * 3 + slot
+                    const int i = q / 3 - i0;
+                    const float w = weight[q];
+#pragma unroll
+                    for (int r = 0; r < ROWS; ++r)
+                        if (r < nr) acc[u][r] += s_go[r * part_len + i] * w;
+                }
+            }
         }
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r)
-            if (r < nr) gp[(size_t)r * m + j] += acc[r];
+        for (int u = 0; u < kTigMaxTargets; ++u) {
+            const int j = j0 + u * kTigThreads + threadIdx.x;
+            if (j >= m) continue;
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r)
+                if (r < nr) gp[(size_t)r * m + j] += acc[u][r];
+        }
     }
 }
 
@@ -643,9 +665,23 @@ extern "C" int epnet_three_nn_ws(int b, int n, int m, const float *unknown, cons
     return check_launch("three_nn indexed");
 }
 
+// runs the unknowns are cut into: the fewest (power of two) that let 8 rows of one run fit LDS, as long as the
+// inverse index keeps at most 16384 keys
+static int tig_parts(int b, int c, int n, int m) {
+    // runs serialise a workgroup's staging; they pay once there are enough workgroups of 8 rows to fill the chip
+    // (B=16, C=256, n=16384 on FP-module indices: 2.86 -> 1.45 ms; B=1: 0.40 -> 0.75 ms)
+    if ((long long)b * div_up(c, 8) < 512) return 1;
+    int parts = 1;
+    while (parts < 16 && (long long)div_up(n, parts) * 4 * 8 > 128 * 1024 && (long long)parts * 2 * m <= 16384) parts *= 2;
+    return parts;
+}
+
 extern "C" size_t epnet_three_interpolate_grad_workspace_bytes(int b, int n, int m) {
     if (b <= 0 || n <= 0 || m <= 0 || m > 16384 || (long long)n * 4 > 128 * 1024) return 0;
-    return (size_t)b * ((size_t)(m + 1) + (size_t)n * 3) * sizeof(int);
+    // sized for the largest partition the launcher may pick (it depends on the channel count as well)
+    int parts = 1;
+    while (parts < 16 && (long long)parts * 2 * m <= 16384) parts *= 2;
+    return (size_t)b * ((size_t)parts * m + 1 + (size_t)n * 3) * sizeof(int);
 }
 
 extern "C" int epnet_three_interpolate_grad_ws(int b, int c, int n, int m, const float *grad_out, const int *idx,
@@ -659,20 +695,24 @@ extern "C" int epnet_three_interpolate_grad_ws(int b, int c, int n, int m, const
     if (workspace_bytes < need) return EPNET_ENOMEM;
     if (b > 65535) return EPNET_ELIMIT;
     hipStream_t s = (hipStream_t)stream;
+    const int parts = tig_parts(b, c, n, m);
+    const int part_len = div_up(div_up(n, parts), 4) * 4;  // 16-byte rows in LDS
     int *offsets = (int *)workspace;
-    int *perm = offsets + (size_t)b * (m + 1);
-    int rc = csr_build_launch(b, m, n * 3, idx, offsets, perm, s);
+    int *perm = offsets + (size_t)b * ((size_t)parts * m + 1);
+    int rc = csr_build_launch(b, parts * m, n * 3, idx, offsets, perm, s, parts > 1 ? 3 * part_len : 0, m);
     if (rc) return rc;
-    const int fit = (128 * 1024) / (n * 4);
+    const int fit = (128 * 1024) / (part_len * 4);
     const int rows = fit >= 8 ? 8 : fit >= 4 ? 4 : fit >= 2 ? 2 : 1;
-    const size_t lds = (size_t)rows * n * 4;
+    const size_t lds = (size_t)rows * part_len * 4;
     dim3 grid(div_up(c, rows), b);
+#define EPNET_TIG(R_) hipLaunchKernelGGL(three_interpolate_grad_csr_kernel<R_>, grid, dim3(kTigThreads), lds, s, c, n, m, parts, part_len, grad_out, weight, offsets, perm, grad_points)
     switch (rows) {
-        case 8: hipLaunchKernelGGL(three_interpolate_grad_csr_kernel<8>, grid, dim3(kTigThreads), lds, s, c, n, m, grad_out, weight, offsets, perm, grad_points); break;
-        case 4: hipLaunchKernelGGL(three_interpolate_grad_csr_kernel<4>, grid, dim3(kTigThreads), lds, s, c, n, m, grad_out, weight, offsets, perm, grad_points); break;
-        case 2: hipLaunchKernelGGL(three_interpolate_grad_csr_kernel<2>, grid, dim3(kTigThreads), lds, s, c, n, m, grad_out, weight, offsets, perm, grad_points); break;
-        default: hipLaunchKernelGGL(three_interpolate_grad_csr_kernel<1>, grid, dim3(kTigThreads), lds, s, c, n, m, grad_out, weight, offsets, perm, grad_points); break;
+        case 8: EPNET_TIG(8); break;
+        case 4: EPNET_TIG(4); break;
+        case 2: EPNET_TIG(2); break;
+        default: EPNET_TIG(1); break;
     }
+#undef EPNET_TIG
     return check_launch("three_interpolate_grad");
 }
 

@@ -420,7 +420,8 @@ def test_scene_index_is_remembered_per_tensor_object():
     assert p2u.scene_index(dev(rand_cloud(2, 512, seed=9))) is None
 
 
-@pytest.mark.parametrize("b,c,m,n", [(2, 256, 64, 256), (2, 128, 1024, 4096), (1, 7, 50, 333), (2, 16, 9, 2), (2, 40, 4096, 16384)])
+@pytest.mark.parametrize("b,c,m,n", [(2, 256, 64, 256), (2, 128, 1024, 4096), (1, 7, 50, 333), (2, 16, 9, 2), (2, 40, 4096, 16384),
+                                     (1, 4096, 4096, 16384)])   # enough workgroups for the run-partitioned gradient
 def test_three_interpolate_and_grad(oracle, b, c, m, n):
     from epnet_amd import pointnet2_cuda as ext
     rng = np.random.default_rng(c + m)
