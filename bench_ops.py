@@ -95,13 +95,19 @@ def main():
         go = torch.randn((bsz, c, n), generator=g).to(dev); gp = torch.zeros((bsz, c, m), device=dev)
         ms = timeit(lambda: p2.three_interpolate_grad_wrapper(bsz, c, n, m, go, idx, w, gp))
         report("three_interpolate_grad", {"B": bsz, "C": c, "n": n, "m": m}, ms, bsz * (c * n * 4 + n * 24 + c * m * 4))
-    # ---- grouping gradient (level 2: C=96, N=4096, M=1024, ns=32)
+    # ---- grouping gradient (level 2: C=96, N=4096, M=1024, ns=32) on real ball-query neighbour lists
     for bsz in (16,):
+        pts = synth.scenes("kitti", bsz, 4096, seed=11).to(dev)
+        cidx = torch.empty((bsz, 1024), dtype=i32, device=dev)
+        ctr = torch.empty((bsz, 1024, 3), device=dev)
+        p2.sample_centres_wrapper(bsz, 4096, 1024, pts, p2.scene_index(pts), cidx, ctr)
+        idx = torch.empty((bsz, 1024, 32), dtype=i32, device=dev)
+        p2.ball_query_wrapper(bsz, 4096, 1024, 1.0, 32, ctr, pts, idx)
         go = torch.randn((bsz, 96, 1024, 32), generator=g).to(dev)
-        idx = torch.randint(0, 4096, (bsz, 1024, 32), generator=g, dtype=i32).to(dev)
         gp = torch.zeros((bsz, 96, 4096), device=dev)
         ms = timeit(lambda: p2.group_points_grad_wrapper(bsz, 96, 4096, 1024, 32, go, idx, gp))
-        report("group_points_grad", {"B": bsz, "C": 96, "N": 4096, "M": 1024, "ns": 32}, ms, bsz * (96 * 1024 * 32 * 4 + 1024 * 32 * 4 + 96 * 4096 * 4))
+        report("group_points_grad", {"B": bsz, "C": 96, "N": 4096, "M": 1024, "ns": 32}, ms, bsz * (96 * 1024 * 32 * 4 + 1024 * 32 * 4 + 96 * 4096 * 4),
+               "neighbour lists of ball_query(r=1.0) around FPS centres")
     # ---- BASELINE config 5: dense 65536-point scenes, one SA level with nsample = 64 (ball-query stress)
     for bsz in (1, 16):
         n, m, ns, c, radius = 65536, 16384, 64, 64, 0.5
