@@ -36,6 +36,17 @@ __device__ __forceinline__ void store_stream(float *dst, float x, float y, float
     __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(dst));
 }
 
+// sum over the 64 lanes of a wave, result in every lane
+__device__ __forceinline__ float wave_sum_f32(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// lists longer than this are summed by a whole wave instead of their owner thread (inverse-index gradients)
+constexpr int kLongList = 48;
+constexpr int kLongQueue = 512;
+
 }  // namespace epnet
 
 #define EPNET_REQUIRE(cond) \

@@ -300,8 +300,21 @@ __global__ __launch_bounds__(kCsrThreads) void scatter_rows_csr_kernel(int c, in
     offsets += (size_t)bs * (n + 1);
     perm += (size_t)bs * p;
     float *gp = grad_points + ((size_t)bs * c + c0) * n;
+    // list lengths are very uneven on real neighbour lists (ball-query padding repeats one index up to nsample
+    // times): a thread sums its own short lists, lists longer than kLongList are queued and summed by whole waves
+    __shared__ int s_long[kLongQueue];
+    __shared__ int s_nlong;
+    if (threadIdx.x == 0) s_nlong = 0;
+    __syncthreads();
     for (int j = threadIdx.x; j < n; j += kCsrThreads) {
         const int beg = offsets[j], end = offsets[j + 1];
+        if (end - beg > kLongList) {
+            const int slot = atomicAdd(&s_nlong, 1);
+            if (slot < kLongQueue) {
+                s_long[slot] = j;
+                continue;
+            }
+        }
         float acc[ROWS];
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
@@ -314,6 +327,27 @@ __global__ __launch_bounds__(kCsrThreads) void scatter_rows_csr_kernel(int c, in
 #pragma unroll
         for (int r = 0; r < ROWS; ++r)
             if (r < nr) gp[(size_t)r * n + j] += acc[r];
+    }
+    __syncthreads();
+    const int nlong = min(s_nlong, kLongQueue);
+    const int lane = threadIdx.x & 63;
+    for (int li = threadIdx.x >> 6; li < nlong; li += kCsrThreads / 64) {
+        const int j = s_long[li];
+        const int beg = offsets[j], end = offsets[j + 1];
+        float acc[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
+        for (int t = beg + lane; t < end; t += 64) {
+            const int q = perm[t];
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r)
+                if (r < nr) acc[r] += s_go[r * p + q];
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const float sum = wave_sum_f32(acc[r]);
+            if (r < nr && lane == 0) gp[(size_t)r * n + j] += sum;
+        }
     }
 }
 

@@ -497,6 +497,8 @@ __global__ __launch_bounds__(kTigThreads) void three_interpolate_grad_csr_kernel
                                                                                const int *__restrict__ perm,
                                                                                float *__restrict__ grad_points) {
     extern __shared__ float s_go[];  // ROWS * part_len floats
+    __shared__ int s_long[kLongQueue];
+    __shared__ int s_nlong;
     const int bs = blockIdx.y;
     const int c0 = blockIdx.x * ROWS;
     const int nr = min(ROWS, c - c0);
@@ -525,11 +527,20 @@ __global__ __launch_bounds__(kTigThreads) void three_interpolate_grad_csr_kernel
                 }
             }
             __syncthreads();
+            if (threadIdx.x == 0) s_nlong = 0;
+            __syncthreads();
 #pragma unroll
             for (int u = 0; u < kTigMaxTargets; ++u) {
                 const int j = j0 + u * kTigThreads + threadIdx.x;
                 if (j >= m) continue;
                 const int beg = offsets[part * m + j], end = offsets[part * m + j + 1];
+                if (end - beg > kLongList) {  // summed by a whole wave below
+                    const int slot = atomicAdd(&s_nlong, 1);
+                    if (slot < kLongQueue) {
+                        s_long[slot] = j;
+                        continue;
+                    }
+                }
                 for (int t = beg; t < end; ++t) {
                     const int q = perm[t];  // = unknown * 3 + slot
                     const int i = q / 3 - i0;
@@ -539,7 +550,33 @@ __global__ __launch_bounds__(kTigThreads) void three_interpolate_grad_csr_kernel
                         if (r < nr) acc[u][r] += s_go[r * part_len + i] * w;
                 }
             }
+            __syncthreads();
+            // the FPS-subset known points near the sensor are nearest to hundreds of unknowns: whole waves take them
+            const int nlong = min(s_nlong, kLongQueue);
+            const int lane = threadIdx.x & 63;
+            for (int li = threadIdx.x >> 6; li < nlong; li += kTigThreads / 64) {
+                const int j = s_long[li];
+                const int beg = offsets[part * m + j], end = offsets[part * m + j + 1];
+                float part_acc[ROWS];
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) part_acc[r] = 0.f;
+                for (int t = beg + lane; t < end; t += 64) {
+                    const int q = perm[t];
+                    const int i = q / 3 - i0;
+                    const float w = weight[q];
+#pragma unroll
+                    for (int r = 0; r < ROWS; ++r)
+                        if (r < nr) part_acc[r] += s_go[r * part_len + i] * w;
+                }
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+                    const float sum = wave_sum_f32(part_acc[r]);
+                    if (r < nr && lane == 0) gp[(size_t)r * m + j] += sum;
+                }
+            }
         }
+        __threadfence_block();
+        __syncthreads();  // the waves' direct additions above land before the owners add their own sums
 #pragma unroll
         for (int u = 0; u < kTigMaxTargets; ++u) {
             const int j = j0 + u * kTigThreads + threadIdx.x;
