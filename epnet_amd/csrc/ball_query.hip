@@ -234,19 +234,31 @@ template <int DPL, typename F>
 __device__ __forceinline__ void bq_walk(int lane, int np, float r2, float cx, float cy, float cz,
                                         const float4 *__restrict__ sorted, const float *__restrict__ boxes,
                                         const float *__restrict__ qboxes, int *quads, F &&visit) {
-    auto scan_bucket = [&](int bb) {
-        const float4 p = sorted[(bb << 6) + lane];
-        const float dx = cx - p.x, dy = cy - p.y, dz = cz - p.z;
-        visit(p, dx * dx + dy * dy + dz * dz);
+    // The kernel is bound by its chain of dependent loads (boxes -> boxes -> points), not by arithmetic: the rows of
+    // up to 4 near buckets are requested together before any of them is tested.
+    auto scan_buckets = [&](unsigned long long cand, auto &&bucket_of) {
+        while (cand) {
+            float4 p[4];
+            int nb = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (cand) {
+                    const int bb = bucket_of((int)__builtin_ctzll(cand));
+                    cand &= cand - 1ull;
+                    p[k] = sorted[(bb << 6) + lane];
+                    nb = k + 1;
+                }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < nb) {
+                    const float dx = cx - p[k].x, dy = cy - p[k].y, dz = cz - p[k].z;
+                    visit(p[k], dx * dx + dy * dy + dz * dz);
+                }
+        }
     };
     if constexpr (DPL <= 2) {  // <= 64 buckets: one round over the bucket boxes, no second level
         const bool bnear = lane < (np >> 6) && box_near(boxes + lane * 6, cx, cy, cz, r2);
-        unsigned long long cand = __ballot(bnear);
-        while (cand) {
-            const int bb = (int)__builtin_ctzll(cand);
-            cand &= cand - 1ull;
-            scan_bucket(bb);
-        }
+        scan_buckets(__ballot(bnear), [](int l) { return l; });
     } else {
         const int nq = np >> 8;
         for (int q0 = 0; q0 < nq; q0 += 64) {
@@ -265,12 +277,7 @@ __device__ __forceinline__ void bq_walk(int lane, int np, float r2, float cx, fl
                     bid = quads[slot] * 4 + (lane & 3);
                     bnear = box_near(boxes + bid * 6, cx, cy, cz, r2);
                 }
-                unsigned long long cand = __ballot(bnear);
-                while (cand) {
-                    const int bb = __builtin_amdgcn_readlane(bid, (int)__builtin_ctzll(cand));
-                    cand &= cand - 1ull;
-                    scan_bucket(bb);
-                }
+                scan_buckets(__ballot(bnear), [&](int l) { return __builtin_amdgcn_readlane(bid, l); });
             }
             __builtin_amdgcn_wave_barrier();
         }
