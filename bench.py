@@ -184,7 +184,7 @@ def op_family(name, head):
     if name.startswith("group_concat_w"):  # the two grouping calls + centre subtraction + concat of the reference, one output
         b, c, n, m, ns = head[:5]
         xyz_part = b * (m * ns * 4 + 3 * n * 4 + 3 * m * ns * 4)
-        return ("group", xyz_part + b * (m * ns * 4 + c * n * 4 + c * m * ns * 4)) if c else ("group_xyz", xyz_part)
+        return "group", xyz_part + (b * (m * ns * 4 + c * n * 4 + c * m * ns * 4) if c else 0)
     if name.startswith("three_nn"):
         b, n, m = head[:3]
         return "three_nn", b * (n * 12 + m * 12 + n * 24)
@@ -199,7 +199,6 @@ FAMILY_KERNELS = {
     "fps N=16384 M=4096": ["epnet::pruned::fps_indexed_kernel<8, 32, false>"],
     "fps N=4096 M=1024": ["epnet::pruned::fps_indexed_kernel<4, 16, false>"],
     "group": ["epnet::group_xyz_centred_vec4_kernel", "epnet::gather_rows_lds_kernel"],
-    "group_xyz": ["epnet::group_xyz_centred_vec4_kernel"],
     "scene_index N=16384": ["epnet::bq_index_kernel<1024, 14>"],
 }
 PMC_PROFILE = os.path.join("profiles", "r01_pmc_traffic.json")
@@ -308,8 +307,9 @@ def main():
     dominant = max(kernels, key=lambda k: kernels[k]["step_ms"])
     fps_note = ("FPS is a chain of M-1 dependent arg-max rounds per scene (latency bound, one workgroup per scene, ~0.6 us per "
                 "round): its HBM fraction is tiny by construction; see roofline_hbm_bound for the bandwidth-bound kernel")
-    grp_note = ("grouping = [grouped xyz - centre ; grouped features] of one MSG scale (epnet_group_concat): random reads from "
-                "LDS-staged rows, 16-byte coalesced writes; write-only ceiling of this grid measured at 6.2 TB/s")
+    grp_note = ("grouping = [grouped xyz - centre ; grouped features] of one MSG scale (epnet_group_concat; the 8 calls of a "
+                "step, 2 of them without features): random reads from LDS-staged rows, 16-byte coalesced writes; a plain "
+                "device-to-device copy on this box runs at device_copy_GBps")
     roofline = roof(dominant, fps_note if dominant.startswith("fps") else grp_note)
     hbm_label = max((k for k in kernels if not k.startswith("fps")), key=lambda k: kernels[k]["step_ms"])
     roofline_hbm = roof(hbm_label, grp_note if hbm_label.startswith("group") else "")

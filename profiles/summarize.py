@@ -11,8 +11,8 @@ into per-op-family tables that can be held against bench.py's own numbers.
       streaming read, so hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024; WRITE_SIZE is exact.
 
 Family = one C-ABI call of the SA stack. The fused grouping call (epnet_group_concat) launches the centred-xyz
-kernel and, when the level has features, the LDS-staged row gather right after it: the pair is one "group" launch,
-a centred-xyz kernel on its own is "group_xyz".
+kernel and, when the level has features, the LDS-staged row gather right after it: either way that is one "group"
+launch.
 """
 import collections
 import csv
@@ -48,7 +48,7 @@ def families(rows):
                 if "gather_rows_lds_kernel" in nxt or "gather_rows_vec4_kernel" in nxt or "gather_rows_scalar" in nxt:
                     fam, idx = "group", [i, i + 1]
                 else:
-                    fam = "group_xyz"
+                    fam = "group"   # a level without features: the centred-xyz kernel is the whole call
             elif "gather_rows" in n:
                 fam = "gather"
             elif "bq_index_kernel" in n:
