@@ -10,6 +10,8 @@
 // scanning as soon as all its centres are full; the block leaves when all its waves have.
 //
 // d2 = (cx-x)*(cx-x) + (cy-y)*(cy-y) + (cz-z)*(cz-z) in source order, no contraction; strict '<'.
+#include <stdlib.h>
+
 #include "common.h"
 #include "spatial.h"
 
@@ -394,6 +396,127 @@ __global__ __launch_bounds__(kQThreads) void bq_query_kernel(int np, int m, BqSc
     }
 }
 
+// TWO centres per wave. The search is a chain of dependent loads (quad boxes -> bucket boxes -> rows) and the chip
+// holds at most 8 waves per SIMD, so a wave that walks the chain for two centres at once -- quad boxes loaded once
+// and tested against both, the bucket boxes of centre 0 in lanes 0-31 and of centre 1 in lanes 32-63, one candidate
+// row of each per step -- halves the latency per centre. Same results as bq_query_kernel.
+template <int DPL, int K>
+__global__ __launch_bounds__(kQThreads) void bq_query2_kernel(int np, int m, BqScales<K> sc,
+                                                              const float *__restrict__ new_xyz,
+                                                              const float4 *__restrict__ sorted,
+                                                              const float *__restrict__ boxes,
+                                                              const float *__restrict__ qboxes) {
+    __shared__ unsigned s_bits[kQThreads / 64][64 * DPL];
+    __shared__ int s_quads[kQThreads / 64][2][64];
+    __shared__ int s_hits[kQThreads / 64][2][K][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bs = blockIdx.y;
+    const int ci0 = (blockIdx.x * (kQThreads / 64) + wave) * 2;
+    if (ci0 >= m) return;  // wave-uniform; no block-level barrier below
+    const bool two = ci0 + 1 < m;
+    sorted += (size_t)bs * np;
+    boxes += (size_t)bs * (np / 64) * 6;
+    qboxes += (size_t)bs * (np / 256) * 6;
+    const float *c0 = new_xyz + ((size_t)bs * m + ci0) * 3;
+    const float *c1 = two ? c0 + 3 : c0;  // an odd tail repeats centre 0 (its second copy is never written)
+    const float ax = c0[0], ay = c0[1], az = c0[2], bx_ = c1[0], by_ = c1[1], bz_ = c1[2];
+    const int half = lane >> 5;  // which centre this lane serves in the bucket-box stage
+    const float hx = half ? bx_ : ax, hy = half ? by_ : ay, hz = half ? bz_ : az;
+    float r2max = sc.r2[0];
+#pragma unroll
+    for (int k = 1; k < K; ++k) r2max = fmaxf(r2max, sc.r2[k]);
+    int cnt[2][K];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int k = 0; k < K; ++k) cnt[e][k] = 0;
+
+    auto visit = [&](int e, const float4 &p) {  // e is compile-time at the call sites
+        const float cx = e ? bx_ : ax, cy = e ? by_ : ay, cz = e ? bz_ : az;
+        const float dx = cx - p.x, dy = cy - p.y, dz = cz - p.z;
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        if (!__ballot(d2 < r2max)) return;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const bool hit = d2 < sc.r2[k];
+            const unsigned long long hm = __ballot(hit);
+            if (hm) {
+                const int pos = cnt[e][k] + popc_below(hm);
+                if (hit && pos < 64) s_hits[wave][e][k][pos] = __float_as_int(p.w);
+                cnt[e][k] += (int)__popcll(hm);
+            }
+        }
+    };
+    // one candidate row of each centre per step (both loads in flight together); bucket_of(e, bit)
+    auto scan_pairs = [&](unsigned long long cand0, unsigned long long cand1, auto &&bucket_of) {
+        while (cand0 | cand1) {
+            float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0, p2 = p0, p3 = p0;
+            const bool h0 = cand0 != 0ull, h1 = cand1 != 0ull;
+            if (h0) { p0 = sorted[(bucket_of(0, (int)__builtin_ctzll(cand0)) << 6) + lane]; cand0 &= cand0 - 1ull; }
+            if (h1) { p1 = sorted[(bucket_of(1, (int)__builtin_ctzll(cand1)) << 6) + lane]; cand1 &= cand1 - 1ull; }
+            const bool h2 = cand0 != 0ull, h3 = cand1 != 0ull;
+            if (h2) { p2 = sorted[(bucket_of(0, (int)__builtin_ctzll(cand0)) << 6) + lane]; cand0 &= cand0 - 1ull; }
+            if (h3) { p3 = sorted[(bucket_of(1, (int)__builtin_ctzll(cand1)) << 6) + lane]; cand1 &= cand1 - 1ull; }
+            if (h0) visit(0, p0);
+            if (h1) visit(1, p1);
+            if (h2) visit(0, p2);
+            if (h3) visit(1, p3);
+        }
+    };
+    if constexpr (DPL <= 2) {  // <= 64 buckets: every bucket box once, tested against both centres
+        bool n0 = false, n1 = false;
+        if (lane < (np >> 6)) {
+            n0 = box_near(boxes + lane * 6, ax, ay, az, r2max);
+            n1 = box_near(boxes + lane * 6, bx_, by_, bz_, r2max);
+        }
+        scan_pairs(__ballot(n0), __ballot(n1), [](int, int bit) { return bit; });
+    } else {
+        const int nq = np >> 8;
+        for (int q0 = 0; q0 < nq; q0 += 64) {
+            const int qd = q0 + lane;
+            bool n0 = false, n1 = false;
+            if (qd < nq) {
+                n0 = box_near(qboxes + qd * 6, ax, ay, az, r2max);
+                n1 = box_near(qboxes + qd * 6, bx_, by_, bz_, r2max);
+            }
+            const unsigned long long qm0 = __ballot(n0), qm1 = __ballot(n1);
+            if (!(qm0 | qm1)) continue;
+            const int nq0 = (int)__popcll(qm0), nq1 = (int)__popcll(qm1);
+            if (n0) s_quads[wave][0][popc_below(qm0)] = qd;
+            if (n1) s_quads[wave][1][popc_below(qm1)] = qd;
+            __builtin_amdgcn_wave_barrier();
+            const int nmine = half ? nq1 : nq0;
+            for (int s0 = 0; s0 < max(nq0, nq1); s0 += 8) {  // 8 candidate quads of each centre per round
+                const int slot = s0 + ((lane & 31) >> 2);
+                int bid = 0;
+                bool bnear = false;
+                if (slot < nmine) {
+                    bid = s_quads[wave][half][slot] * 4 + (lane & 3);
+                    bnear = box_near(boxes + bid * 6, hx, hy, hz, r2max);
+                }
+                const unsigned long long cand = __ballot(bnear);
+                scan_pairs(cand & 0xFFFFFFFFull, cand >> 32,
+                           [&](int e, int bit) { return __builtin_amdgcn_readlane(bid, bit + 32 * e); });
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        if (e == 1 && !two) break;
+        const float cx = e ? bx_ : ax, cy = e ? by_ : ay, cz = e ? bz_ : az;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            int *out = sc.idx[k] + ((size_t)bs * m + ci0 + e) * sc.nsample[k];
+            if (cnt[e][k] <= 64)
+                bq_emit_list(lane, s_hits[wave][e][k], cnt[e][k], sc.nsample[k], out);
+            else
+                bq_bitmap_search<DPL>(lane, np, sc.r2[k], sc.nsample[k], cx, cy, cz, sorted, boxes, qboxes, out, s_bits[wave],
+                                      s_quads[wave][0]);
+        }
+    }
+}
+
 }  // namespace epnet
 
 using namespace epnet;
@@ -441,6 +564,24 @@ static int bq_query_launch(int b, int np, int m, const BqScales<K> &sc, const fl
                            hipStream_t s) {
     const float *boxes = (const float *)(sorted + (size_t)b * np);
     const float *qboxes = boxes + (size_t)b * (np / 64) * 6;
+    // enough centres to fill the chip: two per wave (half the latency per centre); EPNET_BQ_PAIR=0/1 forces either
+    const char *pair_str = getenv("EPNET_BQ_PAIR");
+    const int pair_env = pair_str ? atoi(pair_str) : -1;
+    const bool pair = pair_env >= 0 ? pair_env != 0 : (long long)b * m >= 65536;
+    if (pair) {
+        dim3 grid(div_up(div_up(m, 2), kQThreads / 64), b);
+#define EPNET_BQ2(D_) hipLaunchKernelGGL((bq_query2_kernel<D_, K>), grid, dim3(kQThreads), 0, s, np, m, sc, new_xyz, sorted, boxes, qboxes)
+        switch (np / 2048) {
+            case 1: EPNET_BQ2(1); break;
+            case 2: EPNET_BQ2(2); break;
+            case 4: EPNET_BQ2(4); break;
+            case 8: EPNET_BQ2(8); break;
+            case 16: EPNET_BQ2(16); break;
+            default: EPNET_BQ2(32); break;
+        }
+#undef EPNET_BQ2
+        return check_launch("ball_query query");
+    }
     dim3 grid(div_up(m, kQThreads / 64), b);
 #define EPNET_BQ(D_) hipLaunchKernelGGL((bq_query_kernel<D_, K>), grid, dim3(kQThreads), 0, s, np, m, sc, new_xyz, sorted, boxes, qboxes)
     switch (np / 2048) {

@@ -173,8 +173,10 @@ def test_fps_over_scene_index_ties(oracle):
     (2, 4096, 128, ((0.5, 16), (1.0, 32), (2.0, 8)), "kitti"),   # three scales: one launch per scale
     (2, 500, 100, ((0.8, 16), (1.6, 32)), "kitti"),              # below the indexed range
 ])
-def test_ball_queries_of_an_msg_level_in_one_launch(oracle, b, n, m, scales, kind):
+@pytest.mark.parametrize("pair", ["0", "1"])   # one / two centres per wave (the library picks by launch size)
+def test_ball_queries_of_an_msg_level_in_one_launch(oracle, b, n, m, scales, kind, pair, monkeypatch):
     from epnet_amd import pointnet2_cuda as ext
+    monkeypatch.setenv("EPNET_BQ_PAIR", pair)
     xyz = rand_cloud(b, n, seed=700 + n, kind=kind)
     centres = np.ascontiguousarray(xyz[:, :: max(1, n // m)][:, :m])
     d_xyz, d_c = dev(xyz), dev(centres)
@@ -217,7 +219,9 @@ def test_one_scene_index_serves_sampling_and_both_ball_queries(oracle):
     (1, 5000, 13, 100.0, 128, "ubox"),                                   # every ball saturates at once
     (1, 65536, 300, 0.5, 64, "kitti"), (1, 40000, 100, 0.8, 48, "kitti"),  # config-5 size: largest indexed path
 ])
-def test_ball_query_matches_oracle(oracle, b, n, m, radius, ns, kind):
+@pytest.mark.parametrize("pair", ["0", "1"])
+def test_ball_query_matches_oracle(oracle, b, n, m, radius, ns, kind, pair, monkeypatch):
+    monkeypatch.setenv("EPNET_BQ_PAIR", pair)
     from epnet_amd import pointnet2_utils as p2u
     xyz = rand_cloud(b, n, seed=200 + n + m, kind=kind)
     centres = np.ascontiguousarray(xyz[:, np.random.default_rng(n).permutation(n)[:m]])
