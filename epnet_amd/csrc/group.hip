@@ -70,7 +70,11 @@ __global__ __launch_bounds__(kGThreads) void gather_rows_scalar_kernel(int c, in
 // instruction, and the kernel runs at the rate of its 16-byte coalesced stores. Measured on random
 // indices (C=96, N=4096, P=32768, B=64): direct gather 1.9 TB/s, this kernel see profiles/.
 // grid: (tiles, row chunks, scenes); dynamic LDS: R * n floats; p % 4 == 0.
-__global__ __launch_bounds__(kGThreads) void gather_rows_lds_kernel(int c, int n, int p, int rows, int tile, size_t ostride,
+#ifndef EPNET_GATHER_LDS_THREADS
+#define EPNET_GATHER_LDS_THREADS 256
+#endif
+constexpr int kGLdsThreads = EPNET_GATHER_LDS_THREADS;
+__global__ __launch_bounds__(kGLdsThreads) void gather_rows_lds_kernel(int c, int n, int p, int rows, int tile, size_t ostride,
                                                                     const float *__restrict__ points,
                                                                     const int *__restrict__ idx,
                                                                     float *__restrict__ out) {
@@ -83,15 +87,15 @@ __global__ __launch_bounds__(kGThreads) void gather_rows_lds_kernel(int c, int n
     if ((n & 3) == 0 && ((uintptr_t)src & 15) == 0) {
         const float4 *src4 = reinterpret_cast<const float4 *>(src);
         float4 *dst4 = reinterpret_cast<float4 *>(s_rows);
-        for (int e = threadIdx.x; e < total / 4; e += kGThreads) dst4[e] = src4[e];
+        for (int e = threadIdx.x; e < total / 4; e += kGLdsThreads) dst4[e] = src4[e];
     } else {
-        for (int e = threadIdx.x; e < total; e += kGThreads) s_rows[e] = src[e];
+        for (int e = threadIdx.x; e < total; e += kGLdsThreads) s_rows[e] = src[e];
     }
     __syncthreads();
     const int q_begin = blockIdx.x * tile, q_end = min(p, q_begin + tile);
     const int *ix = idx + (size_t)bs * p;
     float *dst_base = out + (size_t)bs * ostride + (size_t)c0 * p;
-    for (int q = q_begin + threadIdx.x * 4; q < q_end; q += kGThreads * 4) {
+    for (int q = q_begin + threadIdx.x * 4; q < q_end; q += kGLdsThreads * 4) {
         const int4 id = *reinterpret_cast<const int4 *>(ix + q);
         float *dst = dst_base + q;
         const float *row = s_rows;
@@ -204,11 +208,11 @@ static int launch_gather_rows(int b, int c, int n, long long p, const float *poi
         if (tiles > max_tiles) tiles = max_tiles;
         if (tiles < 1) tiles = 1;
         int tile = (int)div_up64(p, tiles);
-        tile = (tile + 1023) / 1024 * 1024;  // whole passes of the workgroup (256 threads x 4 positions)
+        tile = (tile + kGLdsThreads * 4 - 1) / (kGLdsThreads * 4) * (kGLdsThreads * 4);  // whole passes of the workgroup (threads x 4 positions)
         tiles = (int)div_up64(p, tile);
         if (chunks <= 65535) {
             dim3 grid(tiles, chunks, b);
-            hipLaunchKernelGGL(gather_rows_lds_kernel, grid, dim3(kGThreads), (size_t)rows * n * 4, s, c, n, (int)p, rows, tile,
+            hipLaunchKernelGGL(gather_rows_lds_kernel, grid, dim3(kGLdsThreads), (size_t)rows * n * 4, s, c, n, (int)p, rows, tile,
                                ostride, points, idx, out);
             return check_launch(what);
         }

@@ -6,6 +6,6 @@ F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -
 i=0
 while [ $# -gt 0 ]; do
   name=$1; flags=$2; shift 2
-  /opt/rocm/bin/hipcc $F $flags -c fps.hip -o /tmp/fps_$name.o
-  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../scratch/libs/lib_$name.so /tmp/fps_$name.o ../lib/obj/ball_query.o ../lib/obj/group.o ../lib/obj/interpolate.o ../lib/obj/iou3d.o ../lib/obj/roipool3d.o ../lib/obj/host.o
+  /opt/rocm/bin/hipcc $F $flags -c ${SRC:-fps}.hip -o /tmp/${SRC:-fps}_$name.o
+  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../scratch/libs/lib_$name.so /tmp/${SRC:-fps}_$name.o $(ls ../lib/obj/*.o | grep -v "/${SRC:-fps}.o" | tr "\n" " ")
 done

@@ -3,12 +3,12 @@ for v in "$@"; do
   python - <<PY
 import json
 d=json.load(open("gpurun_out/v_$v.json"))
-print("variant $v: step", d["ms_per_step"], "fps1", d["kernels"]["fps N=16384 M=4096"]["avg_ms"], flush=True)
+print("variant $v: step", d["ms_per_step"], "group avg", d["kernels"]["group"]["avg_ms"], flush=True)
 PY
 done
 timeout -k 10 200 python bench.py --cpu-scenes 0 > gpurun_out/v_base.json
 python - <<PY
 import json
 d=json.load(open("gpurun_out/v_base.json"))
-print("variant base: step", d["ms_per_step"], "fps1", d["kernels"]["fps N=16384 M=4096"]["avg_ms"], flush=True)
+print("variant base: step", d["ms_per_step"], "group avg", d["kernels"]["group"]["avg_ms"], flush=True)
 PY
