@@ -56,22 +56,37 @@ __global__ __launch_bounds__(kRpThreads) void roipool3d_kernel(int pts_num, int 
     const int k_end = min(pts_num, (wave + 1) * per_wave * 64);
     int cnt = 0;
     int *mylist = lists + wave * S;
-    for (int k0 = k_begin; k0 < k_end && cnt < S; k0 += 64) {
-        const int k = k0 + lane;
-        bool in = false;
-        if (k < k_end) {
-            const float x = xyz[k * 3 + 0], y = xyz[k * 3 + 1], z = xyz[k * 3 + 2];
-            if (!((fabsf(x - cx) > max_dis) || (fabsf(y - cy) > hh) || (fabsf(z - cz) > max_dis))) {
+    // the scan is a chain of dependent loads, not arithmetic: 8 chunks of 64 points are requested together and then
+    // compacted in index order (positions beyond S are dropped, so testing up to 448 points past the S-th hit
+    // changes nothing)
+    constexpr int kRpChunks = 8;
+    for (int k0 = k_begin; k0 < k_end && cnt < S; k0 += 64 * kRpChunks) {
+        float px[kRpChunks], py[kRpChunks], pz[kRpChunks];
+        bool valid[kRpChunks];
+#pragma unroll
+        for (int u = 0; u < kRpChunks; ++u) {
+            const int k = k0 + u * 64 + lane;
+            valid[u] = k < k_end;
+            const int kk = valid[u] ? k : k_begin;
+            px[u] = xyz[kk * 3 + 0];
+            py[u] = xyz[kk * 3 + 1];
+            pz[u] = xyz[kk * 3 + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < kRpChunks; ++u) {
+            const float x = px[u], y = py[u], z = pz[u];
+            bool in = false;
+            if (valid[u] && !((fabsf(x - cx) > max_dis) || (fabsf(y - cy) > hh) || (fabsf(z - cz) > max_dis))) {
                 const float x_rot = (x - cx) * cosa + (z - cz) * nsina;
                 const float z_rot = (x - cx) * sina + (z - cz) * cosa;
                 in = (x_rot >= -hl) & (x_rot <= hl) & (z_rot >= -hw) & (z_rot <= hw);
             }
-        }
-        const unsigned long long mask = __ballot(in);
-        if (mask) {
-            const int pos = cnt + popc_below(mask);
-            if (in && pos < S) mylist[pos] = k;
-            cnt += (int)__popcll(mask);
+            const unsigned long long mask = __ballot(in);
+            if (mask) {
+                const int pos = cnt + popc_below(mask);
+                if (in && pos < S) mylist[pos] = k0 + u * 64 + lane;
+                cnt += (int)__popcll(mask);
+            }
         }
     }
     if (cnt > S) cnt = S;
@@ -101,12 +116,21 @@ __global__ __launch_bounds__(kRpThreads) void roipool3d_kernel(int pts_num, int 
     // phase 3: copy xyz + features of the S sampled points, one row per wave at a time
     const int row = 3 + feature_in_len;
     float *dst_base = pooled_features + ((size_t)bs * boxes_num + box) * S * row;
-    for (int s = wave; s < S; s += kRpWaves) {
-        const int src = final_idx[s];
-        float *dst = dst_base + (size_t)s * row;
-        const float *sx = xyz + (size_t)src * 3;
-        const float *sf = pts_feature + (size_t)src * feature_in_len;
-        for (int e = lane; e < row; e += 64) dst[e] = e < 3 ? sx[e] : sf[e - 3];
+    // kRpRows rows per wave and step: their gathers are in flight together (the copy is a chain of dependent
+    // loads -- list entry, then the row -- not a bandwidth problem at these sizes)
+    constexpr int kRpRows = 16;
+    for (int s0 = wave * kRpRows; s0 < S; s0 += kRpWaves * kRpRows) {
+        for (int e = lane; e < row; e += 64) {
+            float v[kRpRows];
+#pragma unroll
+            for (int u = 0; u < kRpRows; ++u) {
+                const int src = final_idx[min(s0 + u, S - 1)];
+                v[u] = e < 3 ? xyz[(size_t)src * 3 + e] : pts_feature[(size_t)src * feature_in_len + (e - 3)];
+            }
+#pragma unroll
+            for (int u = 0; u < kRpRows; ++u)
+                if (s0 + u < S) dst_base[(size_t)(s0 + u) * row + e] = v[u];
+        }
     }
 }
 
