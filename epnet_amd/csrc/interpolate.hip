@@ -150,8 +150,7 @@ __global__ __launch_bounds__(kNnIxThreads) void three_nn_indexed_kernel(int n, i
     // per-lane three best (bits(d), k) pairs; d >= +0, so the bit pattern orders like the float
     unsigned d0 = kNone, d1 = kNone, d2 = kNone;
     int i0 = 0x7fffffff, i1 = 0x7fffffff, i2 = 0x7fffffff;
-    auto visit = [&](int b) -> unsigned {
-        const float4 p = sorted[(b << 6) + lane];
+    auto offer = [&](const float4 &p) -> unsigned {
         const float dx = ux - p.x, dy = uy - p.y, dz = uz - p.z;
         const float d = dx * dx + dy * dy + dz * dz;
         const int k = __float_as_int(p.w);
@@ -166,6 +165,7 @@ __global__ __launch_bounds__(kNnIxThreads) void three_nn_indexed_kernel(int n, i
         }
         return db;
     };
+    auto visit = [&](int b) -> unsigned { return offer(sorted[(b << 6) + lane]); };
 
     unsigned bound = kNone;
     for (int b0 = 0; b0 < nb; b0 += 64) {  // nb <= 64 for m <= 4096: one pass
@@ -195,10 +195,19 @@ __global__ __launch_bounds__(kNnIxThreads) void three_nn_indexed_kernel(int n, i
             }
         }
         unsigned long long cand = __ballot(b < nb && L <= bound) & ~done;
-        while (cand) {
-            const int bb = b0 + (int)__builtin_ctzll(cand);
-            cand &= cand - 1ull;
-            visit(bb);
+        while (cand) {  // the rows of up to 4 buckets are requested together (a chain of dependent loads otherwise)
+            float4 p[4];
+            int nbk = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (cand) {
+                    p[k] = sorted[((b0 + (int)__builtin_ctzll(cand)) << 6) + lane];
+                    cand &= cand - 1ull;
+                    nbk = k + 1;
+                }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < nbk) offer(p[k]);
         }
     }
     // pop the wave's three smallest (d, k) pairs: min distance, then min index among its holders
