@@ -281,8 +281,8 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(int boxes_num, float thre
 }
 
 // Greedy sweep of iou3d.cpp:100-116 on the device, one workgroup. For each 64-box tile: wave 0
-// resolves the tile against its diagonal mask words (a 64-step scalar recurrence on readlane'd
-// words) and appends the kept positions; then ALL threads spread the (kept row, later column) mask
+// resolves the tile against its diagonal mask words (fixed-point iteration on wave-wide ORs, see
+// below) and appends the kept positions; then ALL threads spread the (kept row, later column) mask
 // words of the tile over themselves -- independent, coalesced loads -- and OR them into the
 // removed-set words in LDS.
 constexpr int kSweepThreads = 1024;
@@ -298,26 +298,37 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(int boxes_num,
     for (int j = threadIdx.x; j < col_blocks; j += kSweepThreads) remv[j] = 0ull;
     if (threadIdx.x == 0) kept_total = 0;
     __syncthreads();
+    // wave 0 owns the tile's diagonal mask words, one row per lane; the next tile's are requested a tile ahead
+    // (they do not depend on the removed set)
+    unsigned long long diag_next = 0ull;
+    if (threadIdx.x < 64 && threadIdx.x < min(boxes_num, 64)) diag_next = mask[(size_t)threadIdx.x * col_blocks];
     for (int blk = 0; blk < col_blocks; ++blk) {
         const int size = min(boxes_num - blk * 64, 64);
         if (threadIdx.x < 64) {
             const int lane = threadIdx.x;
-            unsigned long long diag = 0ull;
-            if (lane < size) diag = mask[(size_t)(blk * 64 + lane) * col_blocks + blk];
-            const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+            const unsigned long long diag = diag_next;  // bits > lane only (upper triangle)
+            if (blk + 1 < col_blocks && lane < min(boxes_num - (blk + 1) * 64, 64))
+                diag_next = mask[(size_t)((blk + 1) * 64 + lane) * col_blocks + blk + 1];
             unsigned long long alive = ~remv[blk];
             if (size < 64) alive &= (1ull << size) - 1ull;
-            unsigned long long kept = 0ull;
-            for (int i = 0; i < 64; ++i) {
-                if ((alive >> i) & 1ull) {  // wave-uniform
-                    kept |= 1ull << i;
-                    // readlane returns a signed int: go through unsigned, or bit 31 of the low half would
-                    // sign-extend over the whole high half
-                    const unsigned rlo = (unsigned)__builtin_amdgcn_readlane((int)dlo, i);
-                    const unsigned rhi = (unsigned)__builtin_amdgcn_readlane((int)dhi, i);
-                    const unsigned long long row = ((unsigned long long)rhi << 32) | (unsigned long long)rlo;
-                    alive &= ~row;
+            // greedy selection inside the tile: kept_i = alive_i and no kept j < i suppresses i. Solved by iterating
+            // kept <- alive & ~OR{diag_j : j in kept} from kept = alive to its fixed point: bit i is final after i+1
+            // rounds, and overlap chains are short, so this takes a handful of wave-wide ORs instead of a 64-step
+            // chain of cross-lane reads
+            unsigned long long kept = alive;
+            for (int round = 0; round < 64; ++round) {
+                unsigned long long sup = ((kept >> lane) & 1ull) ? diag : 0ull;
+                unsigned lo = (unsigned)sup, hi = (unsigned)(sup >> 32);
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+                    lo |= (unsigned)__shfl_xor((int)lo, off, 64);
+                    hi |= (unsigned)__shfl_xor((int)hi, off, 64);
                 }
+                const unsigned long long next = alive & ~(((unsigned long long)hi << 32) | (unsigned long long)lo);
+                const unsigned long long next_u = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(next >> 32)) << 32) |
+                                                  (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)next);
+                if (next_u == kept) break;
+                kept = next_u;
             }
             const int base = kept_total;
             if ((kept >> lane) & 1ull) {
