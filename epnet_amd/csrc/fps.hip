@@ -403,10 +403,11 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
     __builtin_amdgcn_s_setprio(EPNET_FPS_PRIO);
     EPNET_STATS_BEGIN;
     EPNET_STAMP(t_loop0);
-    // this wave's best point, recomputed only in rounds that changed one of its buckets
+    // this wave's best point(s), recomputed only in rounds that update a bucket holding one of them
     bool stale = true;
     int wbest = kNeg1;
-    unsigned racc = 0xFFFFFFFFu;  // != ~0 in the one lane that publishes
+    unsigned long long hbuckets = 0ull;  // buckets (by summary lane) in which this lane holds the wave's maximum
+    unsigned racc = 0xFFFFFFFFu;  // != ~0 in the lanes that publish
     float xa = 0.f, ya = 0.f, za = 0.f;
     int kb = 1;  // key slot of the round = it % 3
     for (int it = 1; it < m; ++it) {
@@ -416,9 +417,11 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
                     pz = __builtin_amdgcn_fmed3f(cz, loz, hiz);
         const float bdx = px - cx, bdy = py - cy, bdz = pz - cz;
         const float L = bdx * bdx + bdy * bdy + bdz * bdz;
-        unsigned active = fold_parts<PPT>(__ballot(__float_as_int(L) < bm));
+        const unsigned long long act64 = __ballot(__float_as_int(L) < bm);  // bit = summary lane of an active bucket
+        unsigned active = fold_parts<PPT>(act64);
         EPNET_CNT(0, __popc(active));
-        stale = stale || active != 0u;
+        // distances only fall: the wave's maximum and its holders stand unless one of THEIR buckets is updated
+        stale = stale || __ballot((hbuckets & act64) != 0ull) != 0ull;
         EPNET_STAMP(t1);
         // B. update the slots that contain one (handling two slots per iteration was measured: 20 % slower)
         while (active) {
@@ -443,6 +446,7 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
             wbest = wave_max_all(bm);
             unsigned cand = fold_parts<PPT>(__ballot(bm == wbest));
             racc = 0xFFFFFFFFu;
+            hbuckets = 0ull;
             do {
                 const int j = (int)__builtin_ctz(cand);
                 cand &= cand - 1u;
@@ -451,13 +455,17 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
                 const unsigned rw = (unsigned)rk2[j >> 1];
                 __builtin_amdgcn_sched_barrier(0);  // one GPR-index window for the four slot registers
                 const unsigned r = tj == wbest ? ((rw >> ((j & 1) << 4)) & 0xFFFFu) : 0xFFFFFFFFu;
+                if (r != 0xFFFFFFFFu) hbuckets |= 1ull << ((lane & ~(PPT - 1)) | j);  // summary lane of (slot j, my part)
                 const bool take = r < racc;  // a lane holding the maximum in two of its slots keeps the smaller rank
                 racc = take ? r : racc;
                 xa = take ? xj : xa;
                 ya = take ? yj : ya;
                 za = take ? zj : za;
             } while (cand);
-            if (wbest == kNeg1) racc = 0xFFFFFFFFu;  // a wave of padding only
+            if (wbest == kNeg1) {  // a wave of padding only
+                racc = 0xFFFFFFFFu;
+                hbuckets = 0ull;
+            }
         }
         const int buf = it & 1;
         if (racc != 0xFFFFFFFFu) {
