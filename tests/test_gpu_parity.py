@@ -675,6 +675,44 @@ def test_query_and_group_fused_equals_reference_composition():
     assert xr.grad is not None and torch.isfinite(xr.grad).all()
 
 
+def test_backbone_with_shared_indices_equals_plain_ops(monkeypatch):
+    """two MSG SA levels + two FP modules, forward and backward: the wiring of this package's modules (one scene
+    index per level for sampling / multi-scale ball query / three_nn, FPS + centre gather in one call, fused
+    grouping) against the same modules with every shared-index feature switched off"""
+    from epnet_amd import pointnet2_modules as p2m, pointnet2_utils as p2u
+
+    def build():
+        torch.manual_seed(3)
+        sa1 = p2m.PointnetSAModuleMSG(npoint=512, radii=[0.5, 1.0], nsamples=[8, 16], mlps=[[4, 8, 16], [4, 8, 16]]).to(DEV)
+        sa2 = p2m.PointnetSAModuleMSG(npoint=128, radii=[1.0, 2.0], nsamples=[8, 16], mlps=[[32, 32], [32, 48]]).to(DEV)
+        fp2 = p2m.PointnetFPModule(mlp=[80 + 32, 64]).to(DEV)
+        fp1 = p2m.PointnetFPModule(mlp=[64 + 4, 32]).to(DEV)
+        return sa1, sa2, fp2, fp1
+
+    def run(mods, xyz, feats):
+        sa1, sa2, fp2, fp1 = mods
+        f0 = feats.clone().requires_grad_(True)
+        x1, f1, i1 = sa1(xyz, f0)
+        x2, f2, i2 = sa2(x1, f1)
+        u1 = fp2(x1, x2, f1, f2)
+        u0 = fp1(xyz, x1, f0, u1)
+        u0.square().mean().backward()
+        grads = [p.grad.detach().clone() for m in mods for p in m.parameters()]
+        return u0.detach(), i1, i2, f0.grad.detach(), grads
+
+    xyz = dev(rand_cloud(2, 2048, seed=31, kind="kitti"))
+    feats = torch.randn((2, 4, 2048), generator=torch.Generator().manual_seed(4)).to(DEV)
+    with_index = run(build(), xyz, feats)
+    assert p2u.scene_index(xyz, cached_only=True) is not None          # the SA module left its index behind
+    monkeypatch.setattr(p2u, "scene_index", lambda *a, **k: None)      # plain ops: no index anywhere
+    plain = run(build(), xyz, feats)
+    assert torch.equal(with_index[1], plain[1]) and torch.equal(with_index[2], plain[2])   # FPS indices
+    np.testing.assert_allclose(host(with_index[0]), host(plain[0]), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(host(with_index[3]), host(plain[3]), rtol=1e-4, atol=1e-6)
+    for a, b in zip(with_index[4], plain[4]):
+        np.testing.assert_allclose(host(a), host(b), rtol=1e-4, atol=1e-6)
+
+
 def test_autograd_on_gpu():
     from epnet_amd import pointnet2_utils as p2u
     fx = golden("grads.npz")
