@@ -172,6 +172,8 @@ def test_fps_over_scene_index_ties(oracle):
     (2, 3000, 500, ((0.7, 5), (0.7, 9)), "ubox"), (1, 2048, 300, ((100.0, 40), (0.01, 3)), "dup"),
     (2, 4096, 128, ((0.5, 16), (1.0, 32), (2.0, 8)), "kitti"),   # three scales: one launch per scale
     (2, 500, 100, ((0.8, 16), (1.6, 32)), "kitti"),              # below the indexed range
+    (1, 3000, 200, ((5.0, 100), (0.5, 3)), "ubox"),              # nsample beyond the 64-entry hit list
+    (2, 2048, 1, ((1.0, 8), (2.0, 16)), "kitti"), (2, 2048, 3, ((1.0, 8), (2.0, 16)), "kitti"),   # odd tails of the pair kernel
 ])
 @pytest.mark.parametrize("pair", ["0", "1"])   # one / two centres per wave (the library picks by launch size)
 def test_ball_queries_of_an_msg_level_in_one_launch(oracle, b, n, m, scales, kind, pair, monkeypatch):
