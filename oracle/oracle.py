@@ -56,10 +56,12 @@ def opt_n_threads(n):
     return int(lib().oracle_opt_n_threads(int(n)))
 
 
-def furthest_point_sampling(xyz, npoint, return_temp=False):
+def furthest_point_sampling(xyz, npoint, return_temp=False, temp=None):
+    """temp: optional (b, n) running distances to start from (the extension's in/out buffer, sampling.cpp:36-46);
+    default 1e10 everywhere, as pointnet2_utils.py:26 fills it"""
     xyz = _f32(xyz)
     b, n, _ = xyz.shape
-    temp = np.full((b, n), 1e10, dtype=np.float32)
+    temp = np.full((b, n), 1e10, dtype=np.float32) if temp is None else _f32(temp).copy()
     idx = np.zeros((b, npoint), dtype=np.int32)
     lib().oracle_furthest_point_sampling(b, n, npoint, _p(xyz), _p(temp), _p(idx))
     return (idx, temp) if return_temp else idx

@@ -85,6 +85,26 @@ def test_fps_running_distance_buffer_and_streaming_path(oracle):
         np.testing.assert_array_equal(host(temp), o_temp)
 
 
+@pytest.mark.parametrize("n,m", [(700, 50), (4096, 300), (16384, 500), (20000, 60), (70000, 12)])
+def test_fps_continues_from_given_running_distances(oracle, n, m):
+    """temp is an IN/out buffer: a call that starts from arbitrary running distances (here: those another cloud
+    left behind) must give the reference's picks -- every kernel family, indexed and not"""
+    from epnet_amd import pointnet2_cuda as ext
+    xyz = rand_cloud(2, n, seed=n + 5, kind="kitti")
+    start = np.abs(np.random.default_rng(n).standard_normal((2, n))).astype(np.float32) * 30.0
+    o_idx, o_temp = oracle.furthest_point_sampling(xyz, m, return_temp=True, temp=start)
+    d_xyz = dev(xyz)
+    for index in (None, ext.scene_index(d_xyz)):
+        temp = dev(start)
+        idx = torch.empty((2, m), dtype=torch.int32, device=DEV)
+        if index is None:
+            ext.furthest_point_sampling_wrapper(2, n, m, d_xyz, temp, idx)
+        else:
+            ext.furthest_point_sampling_indexed_wrapper(2, n, m, d_xyz, index, temp, idx)
+        np.testing.assert_array_equal(host(idx), o_idx)
+        np.testing.assert_array_equal(host(temp), o_temp)
+
+
 def test_fps_golden_fixtures():
     from epnet_amd import pointnet2_utils as p2u
     fx = golden("pointnet2_cfg1.npz")
