@@ -13,6 +13,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "dpp.h"
 #include "spatial.h"
 
 namespace epnet {
@@ -131,17 +132,68 @@ __global__ __launch_bounds__(kIxThreads) void bq_index_kernel(int n, int np, con
     xyz += (size_t)blockIdx.x * n * 3;
     sorted += (size_t)blockIdx.x * np;
     boxes += (size_t)blockIdx.x * (np / 64) * 6;
-    float lo[3], ext[3];
-    block_bbox3(xyz, n, s_box, lo, ext);
-    const CellGrid g = make_cell_grid(lo, ext, BITS);
-    // counting sort by cell, scattering the points (with their original index) straight to global memory
+    // counting sort by cell, scattering the points (with their original index) straight to global memory.
+    // Up to kIxPerThread points per thread the cloud is read ONCE into registers (bounding box, cell codes and the
+    // scatter all work from there); bigger clouds re-read it per phase.
     constexpr int per = kCells / kIxThreads;
     constexpr int per_shift = per == 16 ? 4 : per == 8 ? 3 : per == 4 ? 2 : -1;
     static_assert(per_shift > 0, "scan layout");
+    constexpr int kIxPerThread = 16;
+    const bool in_regs = n <= kIxThreads * kIxPerThread;  // block-uniform
+    float px[kIxPerThread], py[kIxPerThread], pz[kIxPerThread];
+    float lo[3], ext[3];
+    if (in_regs) {
+        float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+#pragma unroll
+        for (int i = 0; i < kIxPerThread; ++i) {
+            const int k = q + i * kIxThreads;
+            const bool ok = k < n;
+            const int kk = ok ? k : 0;
+            px[i] = xyz[kk * 3 + 0];
+            py[i] = xyz[kk * 3 + 1];
+            pz[i] = xyz[kk * 3 + 2];
+            if (ok) {
+                mn[0] = fminf(mn[0], px[i]); mx[0] = fmaxf(mx[0], px[i]);
+                mn[1] = fminf(mn[1], py[i]); mx[1] = fmaxf(mx[1], py[i]);
+                mn[2] = fminf(mn[2], pz[i]); mx[2] = fmaxf(mx[2], pz[i]);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float l = wave_minf_all(mn[a]), h = wave_maxf_all(mx[a]);
+            if (lane == 0) {
+                s_box[a][wave] = l;
+                s_box[3 + a][wave] = h;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float l = s_box[a][0], h = s_box[3 + a][0];
+            for (int w = 1; w < kIxThreads / 64; ++w) {
+                l = fminf(l, s_box[a][w]);
+                h = fmaxf(h, s_box[3 + a][w]);
+            }
+            lo[a] = l;
+            ext[a] = h - l;
+        }
+    } else {
+        block_bbox3(xyz, n, s_box, lo, ext);
+    }
+    const CellGrid g = make_cell_grid(lo, ext, BITS);
     for (int i = q; i < kCells + kCells / per + 64; i += kIxThreads) s_hist[i] = 0;
     __syncthreads();
-    for (int k = q; k < n; k += kIxThreads)
-        atomicAdd(&s_hist[hist_at((int)cell_code(g, xyz[k * 3 + 0], xyz[k * 3 + 1], xyz[k * 3 + 2]), per_shift)], 1);
+    int code[kIxPerThread];
+    if (in_regs) {
+#pragma unroll
+        for (int i = 0; i < kIxPerThread; ++i) {
+            code[i] = hist_at((int)cell_code(g, px[i], py[i], pz[i]), per_shift);
+            if (q + i * kIxThreads < n) atomicAdd(&s_hist[code[i]], 1);
+        }
+    } else {
+        for (int k = q; k < n; k += kIxThreads)
+            atomicAdd(&s_hist[hist_at((int)cell_code(g, xyz[k * 3 + 0], xyz[k * 3 + 1], xyz[k * 3 + 2]), per_shift)], 1);
+    }
     __syncthreads();
     int sum = 0;
     for (int i = 0; i < per; ++i) sum += s_hist[hist_at(q * per + i, per_shift)];
@@ -157,10 +209,21 @@ __global__ __launch_bounds__(kIxThreads) void bq_index_kernel(int n, int np, con
         base += c;
     }
     __syncthreads();
-    for (int k = q; k < n; k += kIxThreads) {
-        const float x = xyz[k * 3 + 0], y = xyz[k * 3 + 1], z = xyz[k * 3 + 2];
-        const int pos = atomicAdd(&s_hist[hist_at((int)cell_code(g, x, y, z), per_shift)], 1);
-        sorted[pos] = make_float4(x, y, z, __int_as_float(k));
+    if (in_regs) {
+#pragma unroll
+        for (int i = 0; i < kIxPerThread; ++i) {
+            const int k = q + i * kIxThreads;
+            if (k < n) {
+                const int pos = atomicAdd(&s_hist[code[i]], 1);
+                sorted[pos] = make_float4(px[i], py[i], pz[i], __int_as_float(k));
+            }
+        }
+    } else {
+        for (int k = q; k < n; k += kIxThreads) {
+            const float x = xyz[k * 3 + 0], y = xyz[k * 3 + 1], z = xyz[k * 3 + 2];
+            const int pos = atomicAdd(&s_hist[hist_at((int)cell_code(g, x, y, z), per_shift)], 1);
+            sorted[pos] = make_float4(x, y, z, __int_as_float(k));
+        }
     }
     for (int p = n + q; p < np; p += kIxThreads)  // padding: never inside a ball
         sorted[p] = make_float4(3.0e38f, 3.0e38f, 3.0e38f, __int_as_float(-1));
@@ -169,21 +232,15 @@ __global__ __launch_bounds__(kIxThreads) void bq_index_kernel(int n, int np, con
     for (int p = q; p < np; p += kIxThreads) {  // one wave handles one bucket at a time
         const float4 v = sorted[p];
         const bool real = p < n;
-        float mn[3] = {real ? v.x : 3.4e38f, real ? v.y : 3.4e38f, real ? v.z : 3.4e38f};
-        float mx[3] = {real ? v.x : -3.4e38f, real ? v.y : -3.4e38f, real ? v.z : -3.4e38f};
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                mn[a] = fminf(mn[a], __shfl_xor(mn[a], off, 64));
-                mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off, 64));
-            }
+        const float mnx = wave_minf_all(real ? v.x : 3.4e38f), mxx = wave_maxf_all(real ? v.x : -3.4e38f);
+        const float mny = wave_minf_all(real ? v.y : 3.4e38f), mxy = wave_maxf_all(real ? v.y : -3.4e38f);
+        const float mnz = wave_minf_all(real ? v.z : 3.4e38f), mxz = wave_maxf_all(real ? v.z : -3.4e38f);
         if (lane == 0) {
             float *bx = boxes + (p >> 6) * 6;
-            const bool any = mn[0] <= mx[0];  // an all-padding bucket gets a box no ball can reach
-            bx[0] = any ? mn[0] : 3.0e38f; bx[1] = any ? mx[0] : 3.0e38f;
-            bx[2] = any ? mn[1] : 3.0e38f; bx[3] = any ? mx[1] : 3.0e38f;
-            bx[4] = any ? mn[2] : 3.0e38f; bx[5] = any ? mx[2] : 3.0e38f;
+            const bool any = mnx <= mxx;  // an all-padding bucket gets a box no ball can reach
+            bx[0] = any ? mnx : 3.0e38f; bx[1] = any ? mxx : 3.0e38f;
+            bx[2] = any ? mny : 3.0e38f; bx[3] = any ? mxy : 3.0e38f;
+            bx[4] = any ? mnz : 3.0e38f; bx[5] = any ? mxz : 3.0e38f;
         }
     }
     if (!qboxes) return;

@@ -46,4 +46,17 @@ __device__ __forceinline__ unsigned wave_min_all(unsigned v) {
     return min(b[0], b[1]);
 }
 
+// float min / max over the 64 lanes, result in every lane (finite inputs; bit moves on the int pattern)
+__device__ __forceinline__ float wave_minf_all(float v) {
+    v = fminf(v, __int_as_float(dpp_i32<0xB1>(__float_as_int(v))));
+    v = fminf(v, __int_as_float(dpp_i32<0x4E>(__float_as_int(v))));
+    v = fminf(v, __int_as_float(dpp_i32<0x124>(__float_as_int(v))));
+    v = fminf(v, __int_as_float(dpp_i32<0x128>(__float_as_int(v))));
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fminf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fminf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float wave_maxf_all(float v) { return -wave_minf_all(-v); }
+
 }  // namespace epnet
