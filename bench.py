@@ -181,6 +181,12 @@ def op_family(name, head):
     if name.startswith("group_points_w"):
         b, c, n, m, ns = head[:5]
         return ("group_xyz" if c == 3 else "group_feat"), b * (m * ns * 4 + c * n * 4 + c * m * ns * 4)
+    if name.startswith("group_concat_multi"):  # both scales of a level in one call: the bytes of each grouping
+        b, c, n, m, nss = head[:5]
+        total = 0
+        for ns in nss:
+            total += b * (m * ns * 4 + 3 * n * 4 + 3 * m * ns * 4) + (b * (m * ns * 4 + c * n * 4 + c * m * ns * 4) if c else 0)
+        return "group", total
     if name.startswith("group_concat_w"):  # the two grouping calls + centre subtraction + concat of the reference, one output
         b, c, n, m, ns = head[:5]
         xyz_part = b * (m * ns * 4 + 3 * n * 4 + 3 * m * ns * 4)

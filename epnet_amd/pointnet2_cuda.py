@@ -254,6 +254,32 @@ def group_concat_wrapper(b, c, n, npoints, nsample, xyz, new_xyz, features, idx,
     return 1
 
 
+def group_concat_multi_wrapper(b, c, n, npoints, nsamples, xyz, new_xyz, features, idxs, outs, use_xyz):
+    """group_concat_wrapper for all scales of an MSG level in one call (the feature rows are staged once for two scales)"""
+    import ctypes
+    k = len(nsamples)
+    assert len(idxs) == k and len(outs) == k
+    px = dev_ptr(xyz, "xyz", _F) if use_xyz else None
+    pn = dev_ptr(new_xyz, "new_xyz", _F) if use_xyz else None
+    pf = dev_ptr(features, "features", _F) if c else None
+    pis, pos = [], []
+    for ns, i, o in zip(nsamples, idxs, outs):
+        pis.append(dev_ptr(i, "idx", _I)); pos.append(dev_ptr(o, "out", _F))
+        need(i, b * npoints * ns, "idx"); need(o, b * ((3 if use_xyz else 0) + c) * npoints * ns, "out")
+    if use_xyz:
+        need(xyz, b * n * 3, "xyz"); need(new_xyz, b * npoints * 3, "new_xyz")
+    if c:
+        need(features, b * c * n, "features")
+    c_n = (ctypes.c_int * k)(*[int(x) for x in nsamples])
+    c_i = (ctypes.c_void_p * k)(*pis)
+    c_o = (ctypes.c_void_p * k)(*pos)
+    with on_device_of(idxs[0]) as s:
+        _lib.check(_lib.lib().epnet_group_concat_multi(b, c, n, npoints, k, ctypes.cast(c_n, ctypes.c_void_p), px, pn, pf,
+                                                       ctypes.cast(c_i, ctypes.c_void_p), ctypes.cast(c_o, ctypes.c_void_p),
+                                                       int(bool(use_xyz)), s), "group_concat")
+    return 1
+
+
 def group_concat_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_features, use_xyz):
     pg, pi, pp = dev_ptr(grad_out, "grad_out", _F), dev_ptr(idx, "idx", _I), dev_ptr(grad_features, "grad_features", _F)
     need(grad_out, b * ((3 if use_xyz else 0) + c) * npoints * nsample, "grad_out"); need(grad_features, b * c * n, "grad_features")

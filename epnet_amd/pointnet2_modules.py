@@ -53,9 +53,15 @@ class _PointnetSAModuleBase(nn.Module):
         if index is not None and len(self.groupers) > 1 and all(isinstance(g, pointnet2_utils.QueryAndGroup) for g in self.groupers):
             idxs = pointnet2_utils.ball_query_multi([g.radius for g in self.groupers], [g.nsample for g in self.groupers],
                                                     xyz, new_xyz.contiguous(), index)
+        groups = None
+        if (idxs is not None and len({g.use_xyz for g in self.groupers}) == 1 and features is not None
+                and not (torch.is_grad_enabled() and (xyz.requires_grad or new_xyz.requires_grad))):
+            groups = pointnet2_utils.group_concat_multi(xyz, new_xyz, features, idxs, self.groupers[0].use_xyz)
         pooled = []
         for k, (grouper, mlp) in enumerate(zip(self.groupers, self.mlps)):
-            if idxs is not None:
+            if groups is not None:
+                grouped = groups[k]
+            elif idxs is not None:
                 grouped = grouper(xyz, new_xyz, features, index, idxs[k])
             else:
                 grouped = grouper(xyz, new_xyz, features, index) if index is not None else grouper(xyz, new_xyz, features)

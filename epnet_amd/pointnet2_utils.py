@@ -261,6 +261,42 @@ class _GroupConcat(Function):
         return None, None, grad_features, None, None
 
 
+class _GroupConcatMulti(Function):
+    """_GroupConcat for all scales of an MSG level in one call (same tensors; with two scales the feature rows are
+    staged on the chip once for both)"""
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, features, use_xyz, *idxs):
+        batch, npoint = idxs[0].shape[0], idxs[0].shape[1]
+        n = xyz.shape[1]
+        channels = 0 if features is None else features.shape[1]
+        nsamples = [int(i.shape[2]) for i in idxs]
+        outs = [_new(xyz, (batch, (3 if use_xyz else 0) + channels, npoint, ns)) for ns in nsamples]
+        _ext.group_concat_multi_wrapper(batch, channels, n, npoint, nsamples, xyz, new_xyz, features, list(idxs), outs, use_xyz)
+        ctx.for_backwards = (idxs, channels, n, use_xyz)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grad_outs):
+        idxs, channels, n, use_xyz = ctx.for_backwards
+        none = (None,) * (4 + len(idxs))
+        if channels == 0:
+            return none
+        batch = grad_outs[0].shape[0]
+        grad_features = _new(grad_outs[0], (batch, channels, n), zero=True)
+        for idx, g in zip(idxs, grad_outs):   # the gradient op accumulates into its output, like the reference's atomicAdd
+            npoint, nsample = idx.shape[1], idx.shape[2]
+            _ext.group_concat_grad_wrapper(batch, channels, n, npoint, nsample, g.detach().contiguous(), idx, grad_features, use_xyz)
+        return (None, None, grad_features, None) + (None,) * len(idxs)
+
+
+def group_concat_multi(xyz, new_xyz, features, idxs, use_xyz=True):
+    """[grouped xyz - centre ; grouped features] for every neighbour list in `idxs` (one per MSG scale), as
+    QueryAndGroup produces them one by one"""
+    feats = None if features is None else features.contiguous()
+    return list(_GroupConcatMulti.apply(xyz.contiguous(), new_xyz.contiguous(), feats, use_xyz or features is None, *idxs))
+
+
 class QueryAndGroup(nn.Module):
     """ball_query -> group xyz -> subtract the centre -> group features -> concat [xyz(3), features(C)].
     reference: pointnet2_utils.py:231-264. Same values as that composition; the grouped tensor is produced

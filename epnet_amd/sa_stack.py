@@ -78,6 +78,7 @@ class SAStack:
         self.fused_sampling = fused_sampling
         self.tail_scales = int(os.environ.get("EPNET_SA_TAIL_SCALES", "0"))
         self.multi_query = bool(int(os.environ.get("EPNET_SA_MULTI_QUERY", "1")))  # both scales of a level in one launch
+        self.multi_group = bool(int(os.environ.get("EPNET_SA_MULTI_GROUP", "1")))  # both groupings of a level in one call
         self.side = None
         self.npoints, self.radii, self.nsamples, self.feat_channels = npoints, radii, nsamples, feat_channels
         self.with_fp, self.fp = with_fp, fp
@@ -179,10 +180,19 @@ class SAStack:
             for S in L["scales"]:
                 self._query_scale(L, S, cur_xyz, parity)
 
+    def _group_scales(self, L, cur_xyz, parity):
+        """the groupings of all scales of the level: one call (feature rows staged once for both scales)"""
+        if self.fused and self.multi_group:
+            ext.group_concat_multi_wrapper(self.batch, L["c"], L["n"], L["m"], [S["ns"] for S in L["scales"]], cur_xyz,
+                                           L["sets"][parity]["new_xyz"], L["features"], [S["idx"] for S in L["scales"]],
+                                           [S["grouped"] for S in L["scales"]], True)
+        else:
+            for S in L["scales"]:
+                self._group_scale(L, S, cur_xyz, parity)
+
     def _group_level(self, L, cur_xyz, parity):
         self._query_level(L, cur_xyz, parity)
-        for S in L["scales"]:
-            self._group_scale(L, S, cur_xyz, parity)
+        self._group_scales(L, cur_xyz, parity)
 
     def _side_stream(self, device):
         if self.side is None:
@@ -236,8 +246,7 @@ class SAStack:
             for L, cur in deep[1:]:
                 self._query_level(L, cur, 1 - parity)
             for L, cur in deep[1:]:
-                for S in L["scales"]:
-                    self._group_scale(L, S, cur, 1 - parity)
+                self._group_scales(L, cur, 1 - parity)
             if self.tail_scales == 0:
                 self._group_level(first, prev_xyz, 1 - parity)
             else:

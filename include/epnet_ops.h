@@ -138,6 +138,13 @@ int epnet_three_interpolate(int b, int c, int m, int n, const float *points, con
 int epnet_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out, const int *idx,
                                  const float *weight, float *grad_points, epnet_stream_t stream);
 
+/* the groupings of all scales of an MSG level in one call (two scales: the feature rows are staged in LDS once for both).
+ * nsamples / idx / out are HOST arrays of nscales entries; out[k] is (b, 3+c | c, npoints, nsamples[k]). Same results as
+ * nscales calls of epnet_group_concat. */
+int epnet_group_concat_multi(int b, int c, int n, int npoints, int nscales, const int *nsamples, const float *xyz,
+                             const float *new_xyz, const float *features, const int *const *idx, float *const *out,
+                             int use_xyz, epnet_stream_t stream);
+
 /* atomic-free form of the above with caller scratch (inverse index over the known points); 0 bytes = not used */
 size_t epnet_three_interpolate_grad_workspace_bytes(int b, int n, int m);
 int epnet_three_interpolate_grad_ws(int b, int c, int n, int m, const float *grad_out, const int *idx,

@@ -20,6 +20,10 @@ def _calls(fused, multi):
             calls.append(("ball_query_multi_wrapper", (1, n, m, list(radii), list(nss))))
         else:
             calls += [("ball_query_indexed_wrapper", (1, n, m, r, ns)) for r, ns in zip(radii, nss)]
+        if fused == "multi":
+            calls.append(("group_concat_multi_wrapper", (1, c, n, m, list(nss))))
+            n = m
+            continue
         for ns in nss:
             if fused:
                 calls.append(("group_concat_wrapper", (1, c, n, m, ns)))
@@ -36,7 +40,7 @@ def test_launch_bytes_sum_to_the_survey_figure():
     from epnet_amd import sa_stack
     want = sa_stack.sa_algorithmic_bytes(16384)
     assert want["total"] == 51326720
-    for fused in (False, True):
+    for fused in (False, True, "multi"):
         for multi in (False, True):
             total = sum(bench.op_family(name, head)[1] for name, head in _calls(fused, multi))
             assert total == want["total"], (fused, multi, total)

@@ -735,6 +735,25 @@ def test_backbone_with_shared_indices_equals_plain_ops(monkeypatch):
         np.testing.assert_allclose(host(a), host(b), rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("b,c,n,m,nss", [(48, 96, 4096, 256, (16, 32)), (2, 96, 4096, 1024, (16, 32)), (40, 16, 1024, 128, (16, 20)),
+                                         (3, 8, 700, 64, (8, 4)), (2, 0, 2048, 256, (16, 32))])
+def test_groupings_of_an_msg_level_in_one_call(b, c, n, m, nss):
+    """epnet_group_concat_multi (feature rows staged once for two scales when the launch fills the chip) against one
+    epnet_group_concat per scale: identical tensors"""
+    from epnet_amd import pointnet2_cuda as ext
+    g = torch.Generator().manual_seed(c + n)
+    xyz = dev(rand_cloud(b, n, seed=n + c))
+    new_xyz = xyz[:, :m].contiguous()
+    feats = torch.randn((b, c, n), generator=g).to(DEV) if c else None
+    idxs = [torch.randint(0, n, (b, m, ns), generator=g, dtype=torch.int32).to(DEV) for ns in nss]
+    outs = [torch.full((b, 3 + c, m, ns), float("nan"), device=DEV) for ns in nss]
+    ext.group_concat_multi_wrapper(b, c, n, m, list(nss), xyz, new_xyz, feats, idxs, outs, True)
+    for ns, idx, out in zip(nss, idxs, outs):
+        ref = torch.empty_like(out)
+        ext.group_concat_wrapper(b, c, n, m, ns, xyz, new_xyz, feats, idx, ref, True)
+        assert torch.equal(out, ref)
+
+
 def test_autograd_on_gpu():
     from epnet_amd import pointnet2_utils as p2u
     fx = golden("grads.npz")
