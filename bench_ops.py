@@ -37,6 +37,11 @@ def main():
         ts.sort()
         return ts[len(ts) // 2]
 
+    def timeit_once(fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1)
+
     def report(op, shape, ms, nbytes, note=""):
         print(json.dumps({"op": op, "shape": shape, "ms": round(ms, 4), "algorithmic_bytes": nbytes,
                           "GBps": round(nbytes / (ms * 1e-3) / 1e9, 2), "note": note}), flush=True)
@@ -61,6 +66,57 @@ def main():
     report("boxes_iou3d_gpu", {"Na": 512, "Nb": 20}, timeit(lambda: iou3d_utils.boxes_iou3d_gpu(a, b)), 512 * 20 + 20 * 20 + 512 * 20 * 4, "incl. torch height/volume math")
     a1, b1 = a[:1].contiguous(), b[:1].contiguous()
     report("boxes_iou3d_gpu", {"Na": 1, "Nb": 1}, timeit(lambda: iou3d_utils.boxes_iou3d_gpu(a1, b1)), 44, "launch-latency bound")
+    # ---- ROI augmentation: 2 scenes x 64 ROIs x up to 10 tries -- one launch against the reference's
+    # host loop (proposal_target_layer.py:220-247: per try a single-pair IoU composed of ~15 launches and a device->host
+    # read of the result), restated here on this package's own surface for timing
+    from epnet_amd import proposal_target_layer as ptl
+    k_rois, t_max = 128, 10
+    boxes, _ = synth.proposal_boxes(2 * k_rois, seed=3, num_objects=16, jitter=0.6)
+    rois0, gts0 = boxes[:k_rois].to(dev).contiguous(), boxes[k_rois:].to(dev).contiguous()
+    src0 = torch.rand((k_rois,), generator=g).to(dev)
+    tries = torch.tensor([t_max] * 32 + [1] * 32, dtype=i32).repeat(2).to(dev)
+
+    def batched():
+        keep, noise = ptl.draw_aug_tables(k_rois, t_max, "multiple", dev)
+        return ptl.aug_roi_by_noise_batched(rois0.clone(), gts0, src0, 0.55, keep, noise, tries)
+
+    def host_loop():
+        keep, noise = ptl.draw_aug_tables(k_rois, t_max, "multiple", dev)
+        keep_h = keep.cpu().numpy()
+        out = rois0.clone()
+        n_try = tries.cpu().numpy()
+        launches = 0
+        for k in range(k_rois):
+            temp_iou, cnt, aug = 0.0, 0, out[k]
+            while temp_iou < 0.55 and cnt < n_try[k]:
+                nz = noise[k, cnt]
+                aug = out[k] if keep_h[k, cnt] else torch.cat([out[k, 0:3] + nz[0:3], out[k, 3:6] * nz[3:6], out[k, 6:7] + nz[6:7]])
+                temp_iou = float(iou3d_utils.boxes_iou3d_composed(aug.view(1, 7), gts0[k:k + 1])[0, 0])
+                cnt += 1
+                launches += 1
+            out[k] = aug
+        return launches
+    ms_b = timeit(batched)
+    n_pairs = host_loop()
+    ms_h = timeit(host_loop) if args.reps <= 5 else sorted(timeit_once(host_loop) for _ in range(3))[1]
+    report("aug_roi_by_noise", {"rois": k_rois, "aug_times": t_max, "fg": 64, "bg": 64}, ms_b, k_rois * (28 * 2 + 4 + 4 + t_max * 29 + 28 + 4),
+           "tables drawn on the device + one launch; the reference's host loop over the same ROIs (%d single-pair IoU calls with a "
+           "device->host read each): %.1f ms" % (n_pairs, ms_h))
+    # ---- the whole target layer at BASELINE config 4's per-rank shapes (2 scenes x 512 proposals -> 64 ROIs, 16384 x 128 features)
+    bsz, m, n = 2, 512, 16384
+    rl, gl = [], []
+    for i in range(bsz):
+        bx, _ = synth.proposal_boxes(m + 12, seed=200 + i, num_objects=12, jitter=0.4)
+        gt = torch.zeros((20, 7)); gt[:12] = bx[m:]
+        rl.append(bx[:m]); gl.append(gt)
+    layer_in = {"roi_boxes3d": torch.stack(rl).to(dev), "gt_boxes3d": torch.stack(gl).to(dev),
+                "rpn_xyz": synth.scenes("kitti", bsz, n, seed=9).to(dev), "rpn_features": torch.randn((bsz, n, 128), generator=g).to(dev),
+                "seg_mask": (torch.rand((bsz, n), generator=g) > 0.5).float().to(dev), "pts_depth": (torch.rand((bsz, n), generator=g) * 70).to(dev)}
+    layer = ptl.ProposalTargetLayer()
+    ms = timeit(lambda: layer(layer_in))
+    report("ProposalTargetLayer.forward", {"B": bsz, "proposals": m, "rois": 64, "N": n, "C": 128}, ms,
+           bsz * (n * 12 + n * 130 * 4 + 64 * 28 + 64 * 512 * 133 * 4 + 64 * 4),
+           "IoU + sampling (2 host syncs) + batched augmentation + roipool3d + canonical transform + labels; bytes = the roipool3d figure")
     # ---- roipool3d: (B,16384,3)+(B,16384,130) -> (B,64,512,133)
     for bsz, m in ((2, 64), (1, 100), (16, 64)):
         pts = synth.scenes("kitti", bsz, 16384, seed=5).to(dev)

@@ -246,6 +246,102 @@ __global__ __launch_bounds__(256) void iou3d_pairs_kernel(int k, const float *__
     ans[i] = iou3d_pair(a7, b7);
 }
 
+// ---- ROI augmentation by noise (lib/rpn/proposal_target_layer.py:220-247, aug_roi_by_noise_torch) ----------
+// The reference walks the sampled ROIs one by one on the host: per ROI up to aug_times tries, each a host coin
+// (np.random.rand() < 0.2 keeps the ROI as it is), a noisy box built by five small torch kernels
+// (random_aug_box3d :250-275), a single-pair boxes_iou3d_gpu (another ~15 launches) and a device->host read of the
+// IoU for the loop condition -- up to 640 such round trips per scene. Here the random draws of ALL tries are
+// the caller's tables (drawn on the device with no sync), every (ROI, try) IoU is evaluated by its own lane, and
+// the first try whose IoU ends the reference's loop (`not (iou < pos_thresh)`) is found with one ballot:
+// the same boxes and IoUs as the loop fed with draw [k][cnt] at try cnt of ROI k.
+//   keep_draw (k, aug_times) u8: 1 = "keep the original ROI" (:232-234)
+//   noise (k, aug_times, 7) f32: pos_shift[3], hwl_scale[3], angle_rot -- aug = [xyz + shift, hwl * scale, ry + rot] (:259,274)
+__device__ __forceinline__ void aug_box_of(const float *roi, const float *nz, bool keep, float *aug) {
+#pragma unroll
+    for (int j = 0; j < 7; ++j) aug[j] = roi[j];
+    if (!keep) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) aug[j] = roi[j] + nz[j];
+#pragma unroll
+        for (int j = 3; j < 6; ++j) aug[j] = roi[j] * nz[j];
+        aug[6] = roi[6] + nz[6];
+    }
+}
+
+// TP = tries per ROI rounded up to a power of two (<= 64): 64 / TP ROIs per wave, lane = (roi, try)
+__global__ __launch_bounds__(256) void aug_roi_wave_kernel(int k, int aug_times, int tp, float pos_thresh,
+                                                           float *__restrict__ rois, const float *__restrict__ gts,
+                                                           const float *__restrict__ iou_src, const int *__restrict__ tries,
+                                                           const unsigned char *__restrict__ keep_draw,
+                                                           const float *__restrict__ noise, float *__restrict__ iou_out) {
+    const int lane = lane_id();
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int per_wave = 64 / tp;
+    const int grp = lane / tp, t = lane - grp * tp;
+    const int r = wave * per_wave + grp;
+    const int n_try = r < k ? (tries ? min(max(tries[r], 0), aug_times) : aug_times) : 0;
+    const bool active = t < n_try;
+    float roi[7], gt[7], aug[7], nz[7];
+    bool keep = true;
+    float iou = 0.f;
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            roi[j] = rois[(size_t)r * 7 + j];
+            gt[j] = gts[(size_t)r * 7 + j];
+            nz[j] = noise[((size_t)r * aug_times + t) * 7 + j];
+        }
+        keep = keep_draw[(size_t)r * aug_times + t] != 0;
+        aug_box_of(roi, nz, keep, aug);
+        iou = iou3d_pair(aug, gt);
+    }
+    // the loop runs try t+1 only while temp_iou < pos_thresh (:231): a try ends it when that comparison is false
+    const unsigned long long ends = __ballot(active && !(iou < pos_thresh));
+    const unsigned long long group_mask = (tp == 64 ? ~0ull : ((1ull << tp) - 1)) << (grp * tp);
+    const unsigned long long mine = ends & group_mask;
+    const int last = mine ? (__builtin_ctzll(mine) - grp * tp) : (n_try - 1);
+    __syncthreads();  // every lane has read its ROI before the winners overwrite rows (waves of a block share no ROI,
+                      // lanes of a wave are in lockstep; the barrier only orders the stores after the loads)
+    if (active && t == last) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) rois[(size_t)r * 7 + j] = aug[j];
+        iou_out[r] = keep ? iou_src[r] : iou;  // :243-246
+    }
+    if (r < k && n_try == 0 && t == 0) iou_out[r] = iou_src[r];  // no try ran (cnt == 0, :243): box untouched
+}
+
+// any number of tries: one thread walks the loop of one ROI
+__global__ __launch_bounds__(64) void aug_roi_serial_kernel(int k, int aug_times, float pos_thresh, float *__restrict__ rois,
+                                                            const float *__restrict__ gts, const float *__restrict__ iou_src,
+                                                            const int *__restrict__ tries,
+                                                            const unsigned char *__restrict__ keep_draw,
+                                                            const float *__restrict__ noise, float *__restrict__ iou_out) {
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= k) return;
+    const int n_try = tries ? min(max(tries[r], 0), aug_times) : aug_times;
+    float roi[7], gt[7], aug[7], nz[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        roi[j] = rois[(size_t)r * 7 + j];
+        gt[j] = gts[(size_t)r * 7 + j];
+        aug[j] = roi[j];
+    }
+    float temp_iou = 0.f;
+    int cnt = 0;
+    bool keep = true;
+    while (temp_iou < pos_thresh && cnt < n_try) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) nz[j] = noise[((size_t)r * aug_times + cnt) * 7 + j];
+        keep = keep_draw[(size_t)r * aug_times + cnt] != 0;
+        aug_box_of(roi, nz, keep, aug);
+        temp_iou = iou3d_pair(aug, gt);
+        ++cnt;
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) rois[(size_t)r * 7 + j] = aug[j];
+    iou_out[r] = (cnt == 0 || keep) ? iou_src[r] : temp_iou;
+}
+
 // per-box trigonometry, once per box instead of once per pair
 __global__ __launch_bounds__(256) void box_trig_kernel(int n, const float *__restrict__ boxes, BoxTrig *__restrict__ trig) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -444,4 +540,26 @@ extern "C" int epnet_boxes_iou3d_pairs(int k, const float *boxes_a, const float 
     EPNET_REQUIRE(boxes_a && boxes_b && ans);
     hipLaunchKernelGGL(iou3d_pairs_kernel, dim3(div_up(k, 256)), dim3(256), 0, (hipStream_t)stream, k, boxes_a, boxes_b, ans);
     return check_launch("boxes_iou3d_pairs");
+}
+
+extern "C" int epnet_aug_roi_by_noise(int k, int aug_times, float pos_thresh, float *roi_boxes3d, const float *gt_boxes3d,
+                                      const float *iou3d_src, const int *tries, const unsigned char *keep_draw,
+                                      const float *noise, float *iou_of_rois, epnet_stream_t stream) {
+    EPNET_REQUIRE(k >= 0 && aug_times >= 0);
+    if (k == 0) return EPNET_OK;
+    EPNET_REQUIRE(roi_boxes3d && gt_boxes3d && iou3d_src && iou_of_rois);
+    EPNET_REQUIRE(aug_times == 0 || (keep_draw && noise));
+    hipStream_t s = (hipStream_t)stream;
+    if (aug_times >= 1 && aug_times <= 64 && 0.f < pos_thresh) {  // (the loop starts from temp_iou = 0, :225)
+        int tp = 1;
+        while (tp < aug_times) tp *= 2;
+        const int per_wave = 64 / tp;
+        const int waves = div_up(k, per_wave);
+        hipLaunchKernelGGL(aug_roi_wave_kernel, dim3(div_up(waves, 4)), dim3(256), 0, s, k, aug_times, tp, pos_thresh,
+                           roi_boxes3d, gt_boxes3d, iou3d_src, tries, keep_draw, noise, iou_of_rois);
+    } else {
+        hipLaunchKernelGGL(aug_roi_serial_kernel, dim3(div_up(k, 64)), dim3(64), 0, s, k, aug_times, pos_thresh, roi_boxes3d,
+                           gt_boxes3d, iou3d_src, tries, keep_draw, noise, iou_of_rois);
+    }
+    return check_launch("aug_roi_by_noise");
 }

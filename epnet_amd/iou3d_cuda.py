@@ -53,6 +53,28 @@ def boxes_iou3d_pairs_gpu(boxes_a, boxes_b, ans_iou3d):
     return 1
 
 
+def aug_roi_by_noise_gpu(roi_boxes3d, gt_boxes3d, iou3d_src, keep_draw, noise, pos_thresh, iou_of_rois, tries=None):
+    """the ROI augmentation loop of lib/rpn/proposal_target_layer.py:220-247 for all K ROIs in one launch; roi_boxes3d
+    (K,7) is updated in place; keep_draw (K,T) uint8, noise (K,T,7), tries (K) int32 per-ROI try limits or None (not in
+    the reference extension; see epnet_ops.h)"""
+    k = roi_boxes3d.size(0)
+    t = keep_draw.size(1) if keep_draw is not None else 0
+    pr, pg = dev_ptr(roi_boxes3d, "roi_boxes3d", _F), dev_ptr(gt_boxes3d, "gt_boxes3d", _F)
+    ps, po = dev_ptr(iou3d_src, "iou3d_src", _F), dev_ptr(iou_of_rois, "iou_of_rois", _F)
+    need(roi_boxes3d, k * 7, "roi_boxes3d"); need(gt_boxes3d, k * 7, "gt_boxes3d"); need(iou3d_src, k, "iou3d_src")
+    need(iou_of_rois, k, "iou_of_rois")
+    pk = pn = pt = None
+    if tries is not None:
+        pt = dev_ptr(tries, "tries", torch.int32)
+        need(tries, k, "tries")
+    if t:
+        pk, pn = dev_ptr(keep_draw, "keep_draw", torch.uint8), dev_ptr(noise, "noise", _F)
+        need(keep_draw, k * t, "keep_draw"); need(noise, k * t * 7, "noise")
+    with on_device_of(roi_boxes3d) as s:
+        _lib.check(_lib.lib().epnet_aug_roi_by_noise(k, t, float(pos_thresh), pr, pg, ps, pt, pk, pn, po, s), "aug_roi_by_noise")
+    return 1
+
+
 def _nms_device(fn_name, boxes, thresh):
     """returns (keep_dev int64 (N,), num_keep_dev int32 (1,)), both on the boxes' device, no sync"""
     pb = dev_ptr(boxes, "boxes", _F)

@@ -206,6 +206,20 @@ int epnet_boxes_iou3d(int num_a, const float *boxes_a, int num_b, const float *b
  * does with up to 640 single-pair calls per scene */
 int epnet_boxes_iou3d_pairs(int k, const float *boxes_a, const float *boxes_b, float *ans_iou3d, epnet_stream_t stream);
 
+/* aug_roi_by_noise_torch, lib/rpn/proposal_target_layer.py:220-247, for all k sampled ROIs of
+ * a scene in one launch. The reference's host loop per ROI -- `while temp_iou < pos_thresh and cnt < aug_times`:
+ * coin (keep the ROI, p = 0.2) or random_aug_box3d (:250-275), single-pair boxes_iou3d_gpu, read the IoU back --
+ * takes its random draws from the caller's tables instead of np.random / torch.rand, indexed [roi][try]:
+ * keep_draw (k, aug_times) u8 (1 = keep the original box), noise (k, aug_times, 7) f32 = pos_shift[3], hwl_scale[3],
+ * angle_rot (the noisy box is [xyz + shift, hwl * scale, ry + rot]). roi_boxes3d (k,7) is updated in place with the
+ * box of the last try (:242), iou_of_rois (k) receives iou3d_src[k] when that try kept the ROI (or no try ran) and
+ * the last IoU otherwise (:243-246). gt_boxes3d (k,7) = the ground-truth box assigned to each ROI. tries (k) i32 or
+ * NULL: per-ROI try limit min(tries[i], aug_times) -- foreground ROIs get ROI_FG_AUG_TIMES tries and background ROIs
+ * one (:164-176), so the ROIs of a whole batch go through one launch. */
+int epnet_aug_roi_by_noise(int k, int aug_times, float pos_thresh, float *roi_boxes3d, const float *gt_boxes3d,
+                           const float *iou3d_src, const int *tries, const unsigned char *keep_draw,
+                           const float *noise, float *iou_of_rois, epnet_stream_t stream);
+
 /* bytes of device scratch epnet_nms / epnet_nms_normal need for `boxes_num` boxes */
 size_t epnet_nms_workspace_bytes(int boxes_num);
 

@@ -197,3 +197,52 @@ def roipool3d_cpu(pts, boxes3d, pts_feature, sampled_pts_num):
     lib().oracle_roipool3d_cpu(_p(pts), _p(boxes3d), _p(pts_feature), _p(pooled_pts), _p(pooled_feat), _p(flag),
                                _L(m), _L(n), _L(c), _L(sampled_pts_num))
     return pooled_pts, pooled_feat, flag
+
+
+def boxes_iou3d(boxes_a, boxes_b):
+    """boxes_iou3d_gpu, lib/utils/iou3d/iou3d_utils.py:21-53: (N,7),(M,7) [x,y,z,h,w,l,ry] -> (N,M). The reference's fp32
+    torch composition (boxes3d_to_bev_torch kitti_utils.py:137-150, overlap kernel, height overlap, volumes, clamp,
+    divide) restated with numpy float32 operations in the same order."""
+    a, b = _f32(boxes_a), _f32(boxes_b)
+
+    def bev(x):
+        return np.stack([x[:, 0] - x[:, 5] / 2, x[:, 2] - x[:, 4] / 2, x[:, 0] + x[:, 5] / 2, x[:, 2] + x[:, 4] / 2, x[:, 6]],
+                        1).astype(np.float32)
+    ov = boxes_overlap_bev(bev(a), bev(b))
+    a_top, a_bot = (a[:, 1] - a[:, 3])[:, None], a[:, 1][:, None]
+    b_top, b_bot = (b[:, 1] - b[:, 3])[None, :], b[:, 1][None, :]
+    oh = np.maximum(np.minimum(a_bot, b_bot) - np.maximum(a_top, b_top), np.float32(0))
+    o3 = (ov * oh).astype(np.float32)
+    va, vb = (a[:, 3] * a[:, 4] * a[:, 5])[:, None], (b[:, 3] * b[:, 4] * b[:, 5])[None, :]
+    return (o3 / np.maximum(va + vb - o3, np.float32(1e-7))).astype(np.float32)
+
+
+def aug_roi_by_noise(roi_boxes3d, gt_boxes3d, iou3d_src, keep_draw, noise, pos_thresh, tries=None):
+    """aug_roi_by_noise_torch, lib/rpn/proposal_target_layer.py:220-247, with the random draws of try `cnt` of ROI `k`
+    taken from keep_draw[k, cnt] (the coin `np.random.rand() < 0.2`, :232) and noise[k, cnt] = pos_shift[3],
+    hwl_scale[3], angle_rot (random_aug_box3d :250-275; the box is [xyz + shift, hwl * scale, ry + rot], :259,274).
+    tries[k] bounds the tries of ROI k (aug_times of the call: ROI_FG_AUG_TIMES for foreground, 1 for background).
+    Returns (augmented rois (K,7), iou_of_rois (K))."""
+    rois, gts, src = _f32(roi_boxes3d).copy(), _f32(gt_boxes3d), _f32(iou3d_src)
+    noise = _f32(noise)
+    k_total = rois.shape[0]
+    aug_times = 0 if keep_draw is None else keep_draw.shape[1]
+    out_iou = np.zeros((k_total,), np.float32)
+    thresh = np.float32(pos_thresh)
+    for k in range(k_total):
+        n_try = aug_times if tries is None else min(max(int(tries[k]), 0), aug_times)
+        temp_iou, cnt, keep = np.float32(0), 0, True
+        roi = rois[k].copy()
+        aug = roi
+        while temp_iou < thresh and cnt < n_try:                                    # :231
+            if keep_draw[k, cnt]:
+                aug, keep = roi, True                                               # :233-234
+            else:
+                nz = noise[k, cnt]
+                aug = np.concatenate([roi[0:3] + nz[0:3], roi[3:6] * nz[3:6], roi[6:7] + nz[6:7]]).astype(np.float32)
+                keep = False
+            temp_iou = boxes_iou3d(aug[None], gts[k][None])[0, 0]                   # :238-240
+            cnt += 1
+        rois[k] = aug                                                               # :242
+        out_iou[k] = src[k] if (cnt == 0 or keep) else temp_iou                     # :243-246
+    return rois, out_iou

@@ -100,16 +100,7 @@ def make_modules():
         keep[:len(k)] = torch.from_numpy(k)
         return len(k)
 
-    def _iou3d_np(a, b):  # reference composition (iou3d_utils.py:21-53) on top of the oracle's BEV overlap
-        def bev(x):
-            return np.stack([x[:, 0] - x[:, 5] / 2, x[:, 2] - x[:, 4] / 2, x[:, 0] + x[:, 5] / 2, x[:, 2] + x[:, 4] / 2, x[:, 6]], 1).astype(np.float32)
-        ov = oracle.boxes_overlap_bev(bev(a), bev(b))
-        a_top, a_bot = (a[:, 1] - a[:, 3])[:, None], a[:, 1][:, None]
-        b_top, b_bot = (b[:, 1] - b[:, 3])[None, :], b[:, 1][None, :]
-        oh = np.maximum(np.minimum(a_bot, b_bot) - np.maximum(a_top, b_top), np.float32(0))
-        o3 = (ov * oh).astype(np.float32)
-        va, vb = (a[:, 3] * a[:, 4] * a[:, 5])[:, None], (b[:, 3] * b[:, 4] * b[:, 5])[None, :]
-        return (o3 / np.maximum(va + vb - o3, np.float32(1e-7))).astype(np.float32)
+    _iou3d_np = oracle.boxes_iou3d  # reference composition (iou3d_utils.py:21-53) on top of the oracle's BEV overlap
 
     def boxes_iou3d_fused_gpu(a, b, ans):
         wr(ans, _iou3d_np(_np(a), _np(b)))
@@ -117,6 +108,13 @@ def make_modules():
 
     def boxes_iou3d_pairs_gpu(a, b, ans):
         wr(ans, np.diagonal(_iou3d_np(_np(a), _np(b))).copy())
+        return 1
+
+    def aug_roi_by_noise_gpu(rois, gts, iou_src, keep_draw, noise, pos_thresh, iou_out, tries=None):
+        r, i = oracle.aug_roi_by_noise(_np(rois), _np(gts), _np(iou_src), None if keep_draw is None else _np(keep_draw),
+                                       None if noise is None else _np(noise), pos_thresh, None if tries is None else _np(tries))
+        wr(rois, r)
+        wr(iou_out, i)
         return 1
 
     def nms_device(boxes, thresh):  # epnet_amd.iou3d_cuda's all-device form
@@ -128,7 +126,7 @@ def make_modules():
         return torch.from_numpy(k), torch.tensor([len(k)], dtype=torch.int32)
 
     for f in (boxes_overlap_bev_gpu, boxes_iou_bev_gpu, nms_gpu, nms_normal_gpu, nms_device, nms_normal_device,
-              boxes_iou3d_fused_gpu, boxes_iou3d_pairs_gpu):
+              boxes_iou3d_fused_gpu, boxes_iou3d_pairs_gpu, aug_roi_by_noise_gpu):
         setattr(iou, f.__name__, f)
 
     rp = types.ModuleType("roipool3d_cuda")
