@@ -55,6 +55,8 @@ SIGNATURES = {
     "epnet_boxes_iou3d": (_i, [_i, _vp, _i, _vp, _vp, _vp]),
     "epnet_boxes_iou3d_pairs": (_i, [_i, _vp, _vp, _vp, _vp]),
     "epnet_aug_roi_by_noise": (_i, [_i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "epnet_rpn_proposals_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "epnet_rpn_proposals": (_i, [_i, _i, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
     "epnet_nms_workspace_bytes": (_sz, [_i]),
     "epnet_nms": (_i, [_vp, _i, _f, _vp, _sz, _vp, _vp, _vp]),
     "epnet_nms_normal": (_i, [_vp, _i, _f, _vp, _sz, _vp, _vp, _vp]),

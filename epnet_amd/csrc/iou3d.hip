@@ -343,22 +343,34 @@ __global__ __launch_bounds__(64) void aug_roi_serial_kernel(int k, int aug_times
 }
 
 // per-box trigonometry, once per box instead of once per pair
-__global__ __launch_bounds__(256) void box_trig_kernel(int n, const float *__restrict__ boxes, BoxTrig *__restrict__ trig) {
+// Batched form of all three NMS kernels: group = blockIdx.z (y for the 1-D ones) with `cap` boxes of room per group and
+// the group's box count read from device memory (counts[group], clamped to cap) -- a caller whose counts are produced
+// on the device (the proposal layer) never has to read them back. counts == NULL: one group of boxes_num boxes.
+__global__ __launch_bounds__(256) void box_trig_kernel(int n, const int *__restrict__ counts, int cap,
+                                                       const float *__restrict__ boxes, BoxTrig *__restrict__ trig) {
+    const int grp = blockIdx.y;
+    if (counts) n = min(counts[grp], cap);
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) trig[i] = box_trig(boxes[i * 5 + 4]);
+    if (i < n) trig[(size_t)grp * cap + i] = box_trig(boxes[((size_t)grp * cap + i) * 5 + 4]);
 }
 
 // suppression bit-mask, upper triangle only: one WAVE per (row, 64-column tile) -- each lane owns one
 // pair and the 64-bit mask word is the wave's ballot (the reference gives a thread a whole row of 64
 // pairs, :281-290)
 template <bool ROTATED>
-__global__ __launch_bounds__(256) void nms_mask_kernel(int boxes_num, float thresh, const float *__restrict__ boxes,
-                                                       const BoxTrig *__restrict__ trig,
+__global__ __launch_bounds__(256) void nms_mask_kernel(int boxes_num, const int *__restrict__ counts, int cap, float thresh,
+                                                       const float *__restrict__ boxes, const BoxTrig *__restrict__ trig,
                                                        unsigned long long *__restrict__ mask) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int col_blk = blockIdx.y;
-    if (row >= boxes_num || col_blk < (row >> 6)) return;  // wave-uniform: tiles left of the diagonal are never read
+    const int grp = blockIdx.z;
+    if (counts) boxes_num = min(counts[grp], cap);
+    const int stride = counts ? (cap + 63) / 64 : (boxes_num + 63) / 64;  // mask words per row
+    boxes += (size_t)grp * cap * 5;
+    trig += (size_t)grp * cap;
+    mask += (size_t)grp * cap * stride;
+    if (row >= boxes_num || col_blk < (row >> 6) || col_blk * 64 >= boxes_num) return;  // wave-uniform: tiles left of the diagonal are never read
     const int col = col_blk * 64 + lane;
     bool over = false;
     if (col < boxes_num && col > row) {  // on the diagonal tile only the bits right of the row itself (:281-283)
@@ -372,8 +384,7 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(int boxes_num, float thre
         over = v > thresh;
     }
     const unsigned long long bits = __ballot(over);
-    const int col_blocks = (boxes_num + 63) / 64;
-    if (lane == 0) mask[(size_t)row * col_blocks + col_blk] = bits;
+    if (lane == 0) mask[(size_t)row * stride + col_blk] = bits;
 }
 
 // Greedy sweep of iou3d.cpp:100-116 on the device, one workgroup. For each 64-box tile: wave 0
@@ -382,7 +393,7 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(int boxes_num, float thre
 // words of the tile over themselves -- independent, coalesced loads -- and OR them into the
 // removed-set words in LDS.
 constexpr int kSweepThreads = 1024;
-__global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(int boxes_num,
+__global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(int boxes_num, const int *__restrict__ counts, int cap,
                                                                   const unsigned long long *__restrict__ mask,
                                                                   long long *__restrict__ keep,
                                                                   int *__restrict__ num_keep) {
@@ -390,21 +401,27 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(int boxes_num,
     __shared__ unsigned long long kept_bits;
     __shared__ int kept_total;
     __shared__ unsigned char kept_rows[64];
+    const int grp = blockIdx.x;
+    if (counts) boxes_num = min(counts[grp], cap);
     const int col_blocks = (boxes_num + 63) / 64;
+    const int stride = counts ? (cap + 63) / 64 : col_blocks;  // mask words per row
+    mask += (size_t)grp * cap * stride;
+    keep += (size_t)grp * cap;
+    num_keep += grp;
     for (int j = threadIdx.x; j < col_blocks; j += kSweepThreads) remv[j] = 0ull;
     if (threadIdx.x == 0) kept_total = 0;
     __syncthreads();
     // wave 0 owns the tile's diagonal mask words, one row per lane; the next tile's are requested a tile ahead
     // (they do not depend on the removed set)
     unsigned long long diag_next = 0ull;
-    if (threadIdx.x < 64 && threadIdx.x < min(boxes_num, 64)) diag_next = mask[(size_t)threadIdx.x * col_blocks];
+    if (threadIdx.x < 64 && threadIdx.x < min(boxes_num, 64)) diag_next = mask[(size_t)threadIdx.x * stride];
     for (int blk = 0; blk < col_blocks; ++blk) {
         const int size = min(boxes_num - blk * 64, 64);
         if (threadIdx.x < 64) {
             const int lane = threadIdx.x;
             const unsigned long long diag = diag_next;  // bits > lane only (upper triangle)
             if (blk + 1 < col_blocks && lane < min(boxes_num - (blk + 1) * 64, 64))
-                diag_next = mask[(size_t)((blk + 1) * 64 + lane) * col_blocks + blk + 1];
+                diag_next = mask[(size_t)((blk + 1) * 64 + lane) * stride + blk + 1];
             unsigned long long alive = ~remv[blk];
             if (size < 64) alive &= (1ull << size) - 1ull;
             // greedy selection inside the tile: kept_i = alive_i and no kept j < i suppresses i. Solved by iterating
@@ -443,7 +460,7 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(int boxes_num,
         const int work = nk * ncols;
         for (int w = threadIdx.x; w < work; w += kSweepThreads) {
             const int r = w / ncols, j = blk + 1 + (w - r * ncols);
-            const unsigned long long m = mask[(size_t)(blk * 64 + kept_rows[r]) * col_blocks + j];
+            const unsigned long long m = mask[(size_t)(blk * 64 + kept_rows[r]) * stride + j];
             if (m) atomicOr(&remv[j], m);
         }
         __syncthreads();
@@ -467,17 +484,162 @@ static int nms_impl(const float *boxes, int boxes_num, float thresh, void *works
     unsigned long long *mask = (unsigned long long *)workspace;
     BoxTrig *trig = (BoxTrig *)(mask + (size_t)boxes_num * col_blocks);
     if (ROTATED) {
-        hipLaunchKernelGGL(box_trig_kernel, dim3(div_up(boxes_num, 256)), dim3(256), 0, s, boxes_num, boxes, trig);
+        hipLaunchKernelGGL(box_trig_kernel, dim3(div_up(boxes_num, 256)), dim3(256), 0, s, boxes_num, (const int *)nullptr, boxes_num,
+                           boxes, trig);
         int rc0 = check_launch("nms_trig");
         if (rc0) return rc0;
     }
-    hipLaunchKernelGGL(nms_mask_kernel<ROTATED>, dim3(div_up(boxes_num, 4), col_blocks), dim3(256), 0, s, boxes_num, thresh,
-                       boxes, trig, mask);
+    hipLaunchKernelGGL(nms_mask_kernel<ROTATED>, dim3(div_up(boxes_num, 4), col_blocks), dim3(256), 0, s, boxes_num,
+                       (const int *)nullptr, boxes_num, thresh, boxes, trig, mask);
     int rc = check_launch("nms_mask");
     if (rc) return rc;
-    hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(kSweepThreads), (size_t)col_blocks * 8, s, boxes_num, mask,
-                       (long long *)keep, num_keep);
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(kSweepThreads), (size_t)col_blocks * 8, s, boxes_num, (const int *)nullptr,
+                       boxes_num, mask, (long long *)keep, num_keep);
     return check_launch("nms_sweep");
+}
+
+// `groups` independent NMS problems of at most `cap` boxes each, counts on the device (see the kernels)
+static int nms_groups(bool rotated, int groups, int cap, const int *counts, const float *boxes, float thresh, BoxTrig *trig,
+                      unsigned long long *mask, long long *keep, int *num_keep, hipStream_t s) {
+    const int col_blocks = (cap + 63) / 64;
+    if (col_blocks > 65535 || groups > 65535 || (size_t)col_blocks * 8 > 60 * 1024) return EPNET_ELIMIT;
+    if (rotated) {
+        hipLaunchKernelGGL(box_trig_kernel, dim3(div_up(cap, 256), groups), dim3(256), 0, s, 0, counts, cap, boxes, trig);
+        int rc0 = check_launch("nms_trig");
+        if (rc0) return rc0;
+        hipLaunchKernelGGL(nms_mask_kernel<true>, dim3(div_up(cap, 4), col_blocks, groups), dim3(256), 0, s, 0, counts, cap, thresh,
+                           boxes, trig, mask);
+    } else {
+        hipLaunchKernelGGL(nms_mask_kernel<false>, dim3(div_up(cap, 4), col_blocks, groups), dim3(256), 0, s, 0, counts, cap, thresh,
+                           boxes, trig, mask);
+    }
+    int rc = check_launch("nms_mask");
+    if (rc) return rc;
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(groups), dim3(kSweepThreads), (size_t)col_blocks * 8, s, 0, counts, cap, mask, keep,
+                       num_keep);
+    return check_launch("nms_sweep");
+}
+
+// ---- proposal layer (lib/rpn/proposal_layer.py:15-142) ---------------------------------------
+// The reference walks the scenes on the host: boolean-mask indexing by distance bin (a sync each), top-K slices, NMS (mask
+// to the host, host sweep), more slices, torch.cat, copy into the zero-padded result -- about ten host syncs per scene.
+// Here: (1) one workgroup per scene walks the score-sorted order and compacts the members of each distance bin, in order,
+// up to the bin's pre-NMS budget, and writes their BEV boxes (kitti_utils.boxes3d_to_bev_torch :137-150); (2) the NMS of
+// all (scene, bin) groups runs as one batched mask + sweep with the group sizes read from device memory; (3) one kernel
+// gathers the first post-NMS survivors of bin 0, then of bin 1, into the zero-padded (b, post, 7) / (b, post) results.
+// No value leaves the device. bins == 1 is score_based_proposal (:121-142): one bin that takes every box.
+constexpr int kBinThreads = 1024;
+
+__device__ __forceinline__ int bin_of(float z, int bins) {  // nms_range_list = [0, 40, 80] (:65, :77-80)
+    if (bins == 1) return 0;
+    if (z > 0.f && z <= 40.f) return 0;
+    if (z > 40.f && z <= 80.f) return 1;
+    return -1;
+}
+
+// sel (b, 2, tot): positions IN THE SORTED ORDER of the members of each bin; counts (b*2): members kept for the NMS
+__global__ __launch_bounds__(kBinThreads) void proposal_bin_kernel(int n, int bins, int pre0, int pre1, int cap,
+                                                                   const float *__restrict__ proposals,
+                                                                   const long long *__restrict__ order, int *__restrict__ sel,
+                                                                   int *__restrict__ counts, float *__restrict__ bev) {
+    __shared__ int wave_cnt[2][kBinThreads / 64];
+    __shared__ int base[2];
+    const int scene = blockIdx.x, lane = lane_id(), wave = threadIdx.x >> 6;
+    const int tot = pre0 + pre1;
+    proposals += (size_t)scene * n * 7;
+    order += (size_t)scene * n;
+    int *sel0 = sel + (size_t)scene * 2 * tot, *sel1 = sel0 + tot;
+    if (threadIdx.x < 2) base[threadIdx.x] = 0;
+    __syncthreads();
+    for (int start = 0; start < n; start += kBinThreads) {
+        const int i = start + threadIdx.x;
+        int bin = -1;
+        if (i < n) bin = bin_of(proposals[(size_t)order[i] * 7 + 2], bins);
+        const unsigned long long m0 = __ballot(bin == 0), m1 = __ballot(bin == 1);
+        if (lane == 0) {
+            wave_cnt[0][wave] = __popcll(m0);
+            wave_cnt[1][wave] = __popcll(m1);
+        }
+        __syncthreads();
+        int before0 = base[0], before1 = base[1];
+        for (int w = 0; w < wave; ++w) {
+            before0 += wave_cnt[0][w];
+            before1 += wave_cnt[1][w];
+        }
+        // bin 0 keeps pre0 + pre1 members: the tail serves bin 1 when that area holds no box at all (:92-100)
+        if (bin == 0) {
+            const int pos = before0 + popc_below(m0);
+            if (pos < tot) sel0[pos] = i;
+        } else if (bin == 1) {
+            const int pos = before1 + popc_below(m1);
+            if (pos < pre1) sel1[pos] = i;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int t0 = 0, t1 = 0;
+            for (int w = 0; w < kBinThreads / 64; ++w) {
+                t0 += wave_cnt[0][w];
+                t1 += wave_cnt[1][w];
+            }
+            base[0] += t0;
+            base[1] += t1;
+        }
+        __syncthreads();
+    }
+    const int c0 = base[0], c1 = base[1];
+    const int n0 = min(c0, pre0);
+    int n1 = min(c1, pre1);
+    if (bins == 2 && c1 == 0) {  // "this area doesn't have any points, so use rois of first area" (:92-100)
+        n1 = max(min(c0, tot) - pre0, 0);
+        for (int j = threadIdx.x; j < n1; j += kBinThreads) sel1[j] = sel0[pre0 + j];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        counts[scene * 2] = n0;
+        counts[scene * 2 + 1] = bins == 2 ? n1 : 0;
+    }
+    // BEV boxes of the members, in order: [x - l/2, z - w/2, x + l/2, z + w/2, ry]
+    for (int bin = 0; bin < bins; ++bin) {
+        const int cnt = bin ? n1 : n0;
+        const int *src = bin ? sel1 : sel0;
+        float *dst = bev + ((size_t)scene * 2 + bin) * cap * 5;
+        for (int j = threadIdx.x; j < cnt; j += kBinThreads) {
+            const float *p = proposals + (size_t)order[src[j]] * 7;
+            const float half_l = p[5] / 2, half_w = p[4] / 2;
+            dst[j * 5 + 0] = p[0] - half_l;
+            dst[j * 5 + 1] = p[2] - half_w;
+            dst[j * 5 + 2] = p[0] + half_l;
+            dst[j * 5 + 3] = p[2] + half_w;
+            dst[j * 5 + 4] = p[6];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void proposal_emit_kernel(int n, int pre0, int pre1, int cap, int post0, int post1,
+                                                            const float *__restrict__ proposals, const float *__restrict__ scores,
+                                                            const long long *__restrict__ order, const int *__restrict__ sel,
+                                                            const long long *__restrict__ keep, const int *__restrict__ num_keep,
+                                                            float *__restrict__ ret_bbox3d, float *__restrict__ ret_scores,
+                                                            int *__restrict__ ret_count) {
+    const int scene = blockIdx.x;
+    const int tot = pre0 + pre1, post = post0 + post1;
+    const int k0 = min(num_keep[scene * 2], post0), k1 = min(num_keep[scene * 2 + 1], post1);
+    if (threadIdx.x == 0 && ret_count) ret_count[scene] = k0 + k1;
+    for (int j = threadIdx.x; j < post; j += 256) {
+        float row[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float sc = 0.f;
+        if (j < k0 + k1) {  // the kept boxes of bin 0, then those of bin 1 (torch.cat, :117-118)
+            const int bin = j < k0 ? 0 : 1, pos = j < k0 ? j : j - k0;
+            const int member = (int)keep[((size_t)scene * 2 + bin) * cap + pos];
+            const long long src = order[(size_t)scene * n + sel[((size_t)scene * 2 + bin) * tot + member]];
+#pragma unroll
+            for (int q = 0; q < 7; ++q) row[q] = proposals[((size_t)scene * n + src) * 7 + q];
+            sc = scores[(size_t)scene * n + src];
+        }
+#pragma unroll
+        for (int q = 0; q < 7; ++q) ret_bbox3d[((size_t)scene * post + j) * 7 + q] = row[q];
+        ret_scores[(size_t)scene * post + j] = sc;
+    }
 }
 
 }  // namespace epnet
@@ -563,3 +725,71 @@ extern "C" int epnet_aug_roi_by_noise(int k, int aug_times, float pos_thresh, fl
     }
     return check_launch("aug_roi_by_noise");
 }
+
+namespace {
+struct ProposalPlan {
+    int bins, pre0, pre1, post0, post1, cap, groups;
+    size_t off_counts, off_num_keep, off_sel, off_bev, off_trig, off_keep, off_mask, bytes;
+};
+
+inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+// pre / post budgets of the two distance bins: int(0.7 * total) and the rest (proposal_layer.py:66-69)
+ProposalPlan proposal_plan(int b, int distance_based, int pre_nms_top_n, int post_nms_top_n) {
+    ProposalPlan p;
+    p.bins = distance_based ? 2 : 1;
+    p.pre0 = distance_based ? (int)(pre_nms_top_n * 0.7) : pre_nms_top_n;
+    p.pre1 = pre_nms_top_n - p.pre0;
+    p.post0 = distance_based ? (int)(post_nms_top_n * 0.7) : post_nms_top_n;
+    p.post1 = post_nms_top_n - p.post0;
+    p.cap = p.pre0 > p.pre1 ? p.pre0 : p.pre1;
+    if (p.cap < 1) p.cap = 1;
+    p.groups = b * 2;
+    const size_t g = (size_t)p.groups, cap = (size_t)p.cap, tot = (size_t)(p.pre0 + p.pre1);
+    size_t off = 0;
+    p.off_counts = off;   off = align16(off + g * sizeof(int));
+    p.off_num_keep = off; off = align16(off + g * sizeof(int));
+    p.off_sel = off;      off = align16(off + g * tot * sizeof(int));
+    p.off_bev = off;      off = align16(off + g * cap * 5 * sizeof(float));
+    p.off_trig = off;     off = align16(off + g * cap * sizeof(epnet::BoxTrig));
+    p.off_keep = off;     off = align16(off + g * cap * sizeof(long long));
+    p.off_mask = off;     off = align16(off + g * cap * ((cap + 63) / 64) * sizeof(unsigned long long));
+    p.bytes = off;
+    return p;
+}
+}  // namespace
+
+extern "C" size_t epnet_rpn_proposals_workspace_bytes(int b, int distance_based, int pre_nms_top_n, int post_nms_top_n) {
+    if (b <= 0 || pre_nms_top_n < 0 || post_nms_top_n < 0) return 0;
+    return proposal_plan(b, distance_based, pre_nms_top_n, post_nms_top_n).bytes;
+}
+
+extern "C" int epnet_rpn_proposals(int b, int n, const float *proposals, const float *scores, const int64_t *order,
+                                   int distance_based, int pre_nms_top_n, int post_nms_top_n, float nms_thresh, int rotated,
+                                   void *workspace, size_t workspace_bytes, float *ret_bbox3d, float *ret_scores, int *ret_count,
+                                   epnet_stream_t stream) {
+    EPNET_REQUIRE(b >= 0 && n >= 0 && pre_nms_top_n >= 0 && post_nms_top_n >= 0);
+    if (b == 0 || post_nms_top_n == 0) return EPNET_OK;
+    EPNET_REQUIRE(ret_bbox3d && ret_scores && workspace);
+    EPNET_REQUIRE(n == 0 || (proposals && scores && order));
+    const ProposalPlan p = proposal_plan(b, distance_based, pre_nms_top_n, post_nms_top_n);
+    if (workspace_bytes < p.bytes) return EPNET_ENOMEM;
+    if (b > 32767) return EPNET_ELIMIT;
+    hipStream_t s = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    int *counts = (int *)(ws + p.off_counts), *num_keep = (int *)(ws + p.off_num_keep), *sel = (int *)(ws + p.off_sel);
+    float *bev = (float *)(ws + p.off_bev);
+    BoxTrig *trig = (BoxTrig *)(ws + p.off_trig);
+    long long *keep = (long long *)(ws + p.off_keep);
+    unsigned long long *mask = (unsigned long long *)(ws + p.off_mask);
+    hipLaunchKernelGGL(proposal_bin_kernel, dim3(b), dim3(kBinThreads), 0, s, n, p.bins, p.pre0, p.pre1, p.cap, proposals,
+                       (const long long *)order, sel, counts, bev);
+    int rc = check_launch("rpn_proposals bin");
+    if (rc) return rc;
+    rc = nms_groups(rotated != 0, p.groups, p.cap, counts, bev, nms_thresh, trig, mask, keep, num_keep, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(proposal_emit_kernel, dim3(b), dim3(256), 0, s, n, p.pre0, p.pre1, p.cap, p.post0, p.post1, proposals, scores,
+                       (const long long *)order, sel, keep, num_keep, ret_bbox3d, ret_scores, ret_count);
+    return check_launch("rpn_proposals emit");
+}
+

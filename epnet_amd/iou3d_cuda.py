@@ -75,6 +75,30 @@ def aug_roi_by_noise_gpu(roi_boxes3d, gt_boxes3d, iou3d_src, keep_draw, noise, p
     return 1
 
 
+def rpn_proposals_gpu(proposals, scores, order, distance_based, pre_nms_top_n, post_nms_top_n, nms_thresh, rotated,
+                      ret_bbox3d, ret_scores, ret_count=None):
+    """lib/rpn/proposal_layer.py:34-55 for the whole batch, no host sync: proposals (B,N,7), scores (B,N), order (B,N)
+    int64 (descending scores) -> ret_bbox3d (B,post,7), ret_scores (B,post) (not in the reference extension; see
+    epnet_ops.h)"""
+    b, n = scores.size(0), scores.size(1)
+    pp, ps, po = dev_ptr(proposals, "proposals", _F), dev_ptr(scores, "scores", _F), dev_ptr(order, "order", torch.int64)
+    pb, pr = dev_ptr(ret_bbox3d, "ret_bbox3d", _F), dev_ptr(ret_scores, "ret_scores", _F)
+    need(proposals, b * n * 7, "proposals"); need(order, b * n, "order")
+    need(ret_bbox3d, b * post_nms_top_n * 7, "ret_bbox3d"); need(ret_scores, b * post_nms_top_n, "ret_scores")
+    pc = None
+    if ret_count is not None:
+        pc = dev_ptr(ret_count, "ret_count", torch.int32)
+        need(ret_count, b, "ret_count")
+    l = _lib.lib()
+    ws_bytes = l.epnet_rpn_proposals_workspace_bytes(b, int(bool(distance_based)), pre_nms_top_n, post_nms_top_n)
+    ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=scores.device)
+    with on_device_of(scores) as s:
+        _lib.check(l.epnet_rpn_proposals(b, n, pp, ps, po, int(bool(distance_based)), pre_nms_top_n, post_nms_top_n,
+                                         float(nms_thresh), int(bool(rotated)), ws.data_ptr(), ws.numel(), pb, pr, pc, s),
+                   "rpn_proposals")
+    return 1
+
+
 def _nms_device(fn_name, boxes, thresh):
     """returns (keep_dev int64 (N,), num_keep_dev int32 (1,)), both on the boxes' device, no sync"""
     pb = dev_ptr(boxes, "boxes", _F)

@@ -220,6 +220,20 @@ int epnet_aug_roi_by_noise(int k, int aug_times, float pos_thresh, float *roi_bo
                            const float *iou3d_src, const int *tries, const unsigned char *keep_draw,
                            const float *noise, float *iou_of_rois, epnet_stream_t stream);
 
+/* ProposalLayer.forward after the box decoding, lib/rpn/proposal_layer.py:34-55 with distance_based_proposal :58-119
+ * (distance_based != 0: two bins 0 < z <= 40 and 40 < z <= 80 with 70 % / 30 % of the pre- and post-NMS budgets, the far bin
+ * falling back to the near bin's next boxes when it is empty) or score_based_proposal :121-142 (one bin), for all b
+ * scenes with no host synchronisation. proposals (b,n,7) decoded boxes, scores (b,n), order (b,n)
+ * i64 = positions sorted by descending score (torch.sort, :35). rotated: RPN.NMS_TYPE 'rotate' (nms_gpu) or 'normal'
+ * (nms_normal_gpu) (:104-107; score_based_proposal always uses the rotated one, :137). Results: ret_bbox3d
+ * (b, post_nms_top_n, 7) and ret_scores (b, post_nms_top_n), zero-padded behind the kept boxes (:38-39, :52-54);
+ * ret_count (b) i32 or NULL = kept boxes per scene. */
+size_t epnet_rpn_proposals_workspace_bytes(int b, int distance_based, int pre_nms_top_n, int post_nms_top_n);
+int epnet_rpn_proposals(int b, int n, const float *proposals, const float *scores, const int64_t *order,
+                        int distance_based, int pre_nms_top_n, int post_nms_top_n, float nms_thresh, int rotated,
+                        void *workspace, size_t workspace_bytes, float *ret_bbox3d, float *ret_scores, int *ret_count,
+                        epnet_stream_t stream);
+
 /* bytes of device scratch epnet_nms / epnet_nms_normal need for `boxes_num` boxes */
 size_t epnet_nms_workspace_bytes(int boxes_num);
 

@@ -246,3 +246,48 @@ def aug_roi_by_noise(roi_boxes3d, gt_boxes3d, iou3d_src, keep_draw, noise, pos_t
         rois[k] = aug                                                               # :242
         out_iou[k] = src[k] if (cnt == 0 or keep) else temp_iou                     # :243-246
     return rois, out_iou
+
+
+def rpn_proposals(proposals, scores, order, distance_based, pre_nms_top_n, post_nms_top_n, nms_thresh, rotated):
+    """ProposalLayer.forward after the decoding, lib/rpn/proposal_layer.py:34-55 with distance_based_proposal :58-119 and
+    score_based_proposal :121-142, scene by scene in numpy on top of the oracle's NMS. proposals (B,N,7), scores (B,N),
+    order (B,N) = positions by descending score. Returns (ret_bbox3d (B,post,7), ret_scores (B,post), kept per scene)."""
+    proposals, scores = _f32(proposals), _f32(scores)
+    b = scores.shape[0]
+    ret_b = np.zeros((b, post_nms_top_n, 7), np.float32)
+    ret_s = np.zeros((b, post_nms_top_n), np.float32)
+    count = np.zeros((b,), np.int32)
+
+    def bev_of(x):  # kitti_utils.boxes3d_to_bev_torch :137-150
+        return np.stack([x[:, 0] - x[:, 5] / 2, x[:, 2] - x[:, 4] / 2, x[:, 0] + x[:, 5] / 2, x[:, 2] + x[:, 4] / 2, x[:, 6]],
+                        1).astype(np.float32).reshape(-1, 5)
+
+    for k in range(b):
+        s_ord, p_ord = scores[k][order[k]], proposals[k][order[k]]
+        s_list, p_list = [], []
+        if distance_based:
+            ranges = [0, 40.0, 80.0]                                                                     # :65
+            pre = [0, int(pre_nms_top_n * 0.7), pre_nms_top_n - int(pre_nms_top_n * 0.7)]                # :66-67
+            post = [0, int(post_nms_top_n * 0.7), post_nms_top_n - int(post_nms_top_n * 0.7)]            # :68-69
+            dist = p_ord[:, 2]
+            first_mask = (dist > ranges[0]) & (dist <= ranges[1])
+            for i in (1, 2):
+                m = (dist > ranges[i - 1]) & (dist <= ranges[i])
+                if m.sum() != 0:
+                    cur_s, cur_p = s_ord[m][:pre[i]], p_ord[m][:pre[i]]                                  # :82-91
+                else:
+                    cur_s = s_ord[first_mask][pre[i - 1]:][:pre[i]]                                      # :92-100
+                    cur_p = p_ord[first_mask][pre[i - 1]:][:pre[i]]
+                keep = nms(bev_of(cur_p), nms_thresh, rotated)[:post[i]]                                  # :102-112
+                s_list.append(cur_s[keep])
+                p_list.append(cur_p[keep])
+        else:
+            cur_s, cur_p = s_ord[:pre_nms_top_n], p_ord[:pre_nms_top_n]                                  # :133-134
+            keep = nms(bev_of(cur_p), nms_thresh, True)[:post_nms_top_n]                                  # :136-140
+            s_list.append(cur_s[keep])
+            p_list.append(cur_p[keep])
+        s_all, p_all = np.concatenate(s_list), np.concatenate(p_list).reshape(-1, 7)
+        ret_b[k, :len(s_all)] = p_all                                                                     # :52-54
+        ret_s[k, :len(s_all)] = s_all
+        count[k] = len(s_all)
+    return ret_b, ret_s, count

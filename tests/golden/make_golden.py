@@ -26,6 +26,8 @@ import sys
 import numpy as np
 import torch
 
+sys.dont_write_bytecode = True  # importing the reference must not leave __pycache__ files in /root/reference
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)

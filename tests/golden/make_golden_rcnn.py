@@ -20,6 +20,8 @@ import types
 import numpy as np
 import torch
 
+sys.dont_write_bytecode = True  # importing the reference must not leave __pycache__ files in /root/reference
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
@@ -62,6 +64,7 @@ def import_reference():
     torch.cuda.FloatTensor = torch.FloatTensor
     torch.cuda.IntTensor = torch.IntTensor
     torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.Tensor.get_device = lambda self: self.device  # `anchor_size.to(roi_box3d.get_device())`, bbox_transform.py:41: -1 on the CPU
     install_easydict()
     oracle_ext.install_as_top_level()
     sys.path.insert(0, REF)
@@ -136,6 +139,53 @@ def scene_boxes(num_roi, num_gt, seed):
     rois = (src + noise).float()
     rois[:, 3:6] = rois[:, 3:6].clamp(min=0.5)
     return rois.contiguous(), gt.float().contiguous()
+
+
+def proposal_layer_fixture(cfg, pl, bt):
+    """the reference's ProposalLayer (lib/rpn/proposal_layer.py) and decode_bbox_target (lib/utils/bbox_transform.py) on
+    small scenes: distance-based with axis-aligned NMS (TRAIN), distance-based with rotated NMS (TEST), score-based; one
+    scene has no point beyond 40 m (the far bin falls back to the near bin's next boxes, :92-100)"""
+    out = {}
+    g = torch.Generator().manual_seed(81)
+    b, n = 2, 1024
+    cfg.RPN.LOC_XZ_FINE, cfg.RPN.LOC_SCOPE, cfg.RPN.LOC_BIN_SIZE, cfg.RPN.NUM_HEAD_BIN = True, 3.0, 0.5, 12
+    cfg.CLS_MEAN_SIZE = np.array([[1.52563191462, 1.62856739989, 3.88311640418]], dtype=np.float32)
+    xyz = synth.scenes("kitti", b, n, seed=82)
+    xyz[1, :, 2] = xyz[1, :, 2] * 0.5 + 0.5          # scene 1: everything within 40 m
+    channels = 12 * 4 + 1 + 12 * 2 + 3
+    rpn_reg = (torch.randn((b, n, channels), generator=g) * 0.6).half().float()
+    rpn_scores = torch.randn((b, n), generator=g)
+    out.update({"xyz": _np(xyz), "rpn_reg_f16": _np(rpn_reg.half()), "rpn_scores": _np(rpn_scores)})
+    for avg in (True, False):
+        cfg.TRAIN.BBOX_AVG_BY_BIN = cfg.TEST.BBOX_AVG_BY_BIN = avg
+        dec = bt.decode_bbox_target(xyz.view(-1, 3).clone(), rpn_reg.view(-1, channels).clone(), anchor_size=torch.from_numpy(cfg.CLS_MEAN_SIZE[0]),
+                                    loc_scope=3.0, loc_bin_size=0.5, num_head_bin=12, get_xz_fine=True, get_y_by_bin=False, get_ry_fine=False)
+        out["decode_rpn_avg%d" % avg] = _np(dec)
+    # the RCNN-stage call shape (tools/eval_rcnn.py:568-575): 7-column anchors, rotated back by the ROI's ry, y by offset, fine ry
+    cfg.TRAIN.BBOX_AVG_BY_BIN = cfg.TEST.BBOX_AVG_BY_BIN = False
+    rois = scene_boxes(256, 6, 83)[0]
+    reg_ch = 6 * 4 + 1 + 9 * 2 + 3
+    rcnn_reg = (torch.randn((256, reg_ch), generator=g) * 0.6).half().float()
+    dec = bt.decode_bbox_target(rois.clone(), rcnn_reg.clone(), anchor_size=torch.from_numpy(cfg.CLS_MEAN_SIZE[0]), loc_scope=1.5,
+                                loc_bin_size=0.5, num_head_bin=9, get_xz_fine=True, get_y_by_bin=False, loc_y_scope=0.5,
+                                loc_y_bin_size=0.25, get_ry_fine=True)
+    out.update({"rcnn_rois": _np(rois), "rcnn_reg_f16": _np(rcnn_reg.half()), "decode_rcnn": _np(dec)})
+    cfg.TRAIN.BBOX_AVG_BY_BIN = cfg.TEST.BBOX_AVG_BY_BIN = True
+
+    cases = (("train_normal", "TRAIN", True, "normal", 600, 64, 0.85), ("test_rotate", "TEST", True, "rotate", 300, 40, 0.5),
+             ("train_tight", "TRAIN", True, "normal", 900, 128, 0.3), ("score_based", "TEST", False, "normal", 500, 48, 0.6), ("padded_normal", "TRAIN", True, "normal", 900, 800, 0.05),
+             ("padded_rotate", "TEST", True, "rotate", 1000, 900, 0.02), ("padded_score", "TRAIN", False, "normal", 700, 650, 0.03))
+    for tag, mode, dist_based, nms_type, pre, post, thresh in cases:
+        cfg.TEST.RPN_DISTANCE_BASED_PROPOSE = dist_based
+        cfg.RPN.NMS_TYPE = nms_type
+        cfg[mode].RPN_PRE_NMS_TOP_N, cfg[mode].RPN_POST_NMS_TOP_N, cfg[mode].RPN_NMS_THRESH = pre, post, thresh
+        layer = pl.ProposalLayer(mode=mode)
+        boxes, scores = layer(rpn_scores.clone(), rpn_reg.clone(), xyz.clone())
+        out["%s__bbox3d" % tag], out["%s__scores" % tag] = _np(boxes), _np(scores)
+        out["%s__cfg" % tag] = np.array([mode == "TRAIN", dist_based, nms_type == "rotate", pre, post, thresh], dtype=np.float64)
+        print(tag, "kept per scene", [int((boxes[i].abs().sum(1) > 0).sum()) for i in range(b)], "of", post)
+    np.savez_compressed(os.path.join(HERE, "proposal_layer.npz"), **out)
+    print("wrote proposal_layer.npz", os.path.getsize(os.path.join(HERE, "proposal_layer.npz")), "bytes")
 
 
 def main():
@@ -233,6 +283,8 @@ def main():
     for k, v in res.items():
         out["fwd__out_" + k] = _np(v)
     print("forward: non-empty ROIs", int((res["cls_label"] >= 0).sum()), "of", res["cls_label"].numel())
+
+    proposal_layer_fixture(cfg, pl, bt)
 
     np.savez_compressed(os.path.join(HERE, "proposal_target.npz"), **out)
     print("wrote proposal_target.npz", os.path.getsize(os.path.join(HERE, "proposal_target.npz")), "bytes")
