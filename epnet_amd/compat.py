@@ -26,6 +26,13 @@ _SURFACE = {
 }
 
 
+# the "next" rows of SURVEY.md 8(f): the callers either side of the NMS / IoU / pooling ops
+_CALLERS = {
+    "lib.rpn.proposal_layer": "proposal_layer",                  # lib/net/rpn.py:4 imports ProposalLayer from here
+    "lib.rpn.proposal_target_layer": "proposal_target_layer",    # lib/net/rcnn_net.py:5 imports ProposalTargetLayer from here
+}
+
+
 def install_extensions():
     for name in _EXT:
         sys.modules[name] = importlib.import_module("epnet_amd." + name)
@@ -54,6 +61,19 @@ def install_surface(include_kitti_utils=False):
     if include_kitti_utils:  # only the 3 helpers exist here; leave the real module alone if present
         table["lib.utils.kitti_utils"] = "kitti_utils"
     for dotted, local in table.items():
+        _ensure_package(dotted)
+        mod = importlib.import_module("epnet_amd." + local)
+        sys.modules[dotted] = mod
+        parent, leaf = dotted.rsplit(".", 1)
+        setattr(sys.modules[parent], leaf, mod)
+
+
+def install_callers():
+    """serve this package's ProposalLayer / ProposalTargetLayer under the reference's module paths, so that
+    lib/net/rpn.py and lib/net/rcnn_net.py construct them unchanged; both read the reference's ``lib.config.cfg`` when
+    that module is loaded (same attribute names), their own yaml-valued defaults otherwise"""
+    install_extensions()
+    for dotted, local in _CALLERS.items():
         _ensure_package(dotted)
         mod = importlib.import_module("epnet_amd." + local)
         sys.modules[dotted] = mod

@@ -32,11 +32,19 @@ def default_cfg():
                            RPN=rpn, TRAIN=train, TEST=test)
 
 
+def _ambient_cfg():
+    """the reference's global config when its module is loaded in this process (drop-in use under lib/net/*), else the
+    yaml-valued defaults above"""
+    import sys
+    ref = sys.modules.get("lib.config")
+    return ref.cfg if ref is not None and hasattr(ref, "cfg") else default_cfg()
+
+
 class ProposalLayer(nn.Module):
     def __init__(self, mode='TRAIN', cfg=None):
         super().__init__()
         self.mode = mode
-        self.cfg = cfg if cfg is not None else default_cfg()
+        self.cfg = cfg if cfg is not None else _ambient_cfg()
         self.register_buffer("MEAN_SIZE", torch.from_numpy(np.asarray(self.cfg.CLS_MEAN_SIZE[0], dtype=np.float32)), persistent=False)
 
     def _mode_cfg(self):

@@ -101,10 +101,18 @@ def rotate_along_y(xz_rows, angle):
     return xz_rows
 
 
+def _ambient_cfg():
+    """the reference's global config when its module is loaded in this process (drop-in use under lib/net/*), else the
+    yaml-valued defaults above"""
+    import sys
+    ref = sys.modules.get("lib.config")
+    return ref.cfg if ref is not None and hasattr(ref, "cfg") else default_cfg()
+
+
 class ProposalTargetLayer(nn.Module):
     def __init__(self, cfg=None, generator=None):
         super().__init__()
-        self.cfg = cfg if cfg is not None else default_cfg()
+        self.cfg = cfg if cfg is not None else _ambient_cfg()
         self.generator = generator  # device generator for the augmentation draws (None: the default one)
 
     # ------------------------------------------------------------------------------------------------------ forward

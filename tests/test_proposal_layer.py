@@ -172,3 +172,35 @@ def test_proposal_layer_captures_into_a_hip_graph(hiplib):
     torch.cuda.synchronize()
     new_b, new_s = layer(sc, reg, xyz)
     assert torch.equal(gb, new_b) and torch.equal(gs, new_s) and not torch.equal(new_s, eager_s)
+
+
+def test_callers_resolve_under_the_reference_paths_and_read_its_cfg(monkeypatch):
+    """compat.install_callers(): `from lib.rpn.proposal_layer import ProposalLayer` (lib/net/rpn.py:4) and
+    `from lib.rpn.proposal_target_layer import ProposalTargetLayer` (lib/net/rcnn_net.py:5) give this package's classes,
+    constructed the reference's way (`ProposalLayer(mode=...)`, `ProposalTargetLayer()`), reading a loaded lib.config.cfg"""
+    import sys
+    import types
+    from epnet_amd import compat, proposal_layer as pl, proposal_target_layer as ptl
+    saved = {k: sys.modules.get(k) for k in list(sys.modules) if k == "lib" or k.startswith("lib.") or k.endswith("_cuda")}
+    try:
+        compat.install_callers()
+        from lib.rpn.proposal_layer import ProposalLayer
+        from lib.rpn.proposal_target_layer import ProposalTargetLayer
+        assert ProposalLayer is pl.ProposalLayer and ProposalTargetLayer is ptl.ProposalTargetLayer
+        assert ProposalLayer(mode='TEST')._mode_cfg().RPN_POST_NMS_TOP_N == 100        # yaml defaults
+        fake = types.ModuleType("lib.config")
+        fake.cfg = pl.default_cfg()
+        fake.cfg.TEST.RPN_POST_NMS_TOP_N = 77
+        fake.cfg.RCNN = ptl.default_cfg().RCNN
+        fake.cfg.RCNN.ROI_PER_IMAGE = 32
+        fake.cfg.AUG_DATA, fake.cfg.AUG_ROT_RANGE = False, 18
+        monkeypatch.setitem(sys.modules, "lib.config", fake)
+        assert ProposalLayer(mode='TEST')._mode_cfg().RPN_POST_NMS_TOP_N == 77
+        assert ProposalTargetLayer().cfg.RCNN.ROI_PER_IMAGE == 32
+    finally:
+        for k in [k for k in sys.modules if k == "lib" or k.startswith("lib.") or k.endswith("_cuda")]:
+            if k not in saved:
+                del sys.modules[k]
+        for k, v in saved.items():
+            if v is not None:
+                sys.modules[k] = v
