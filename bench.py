@@ -204,7 +204,7 @@ def op_family(name, head):
 FAMILY_KERNELS = {
     "fps N=16384 M=4096": ["epnet::pruned::fps_indexed_kernel<8, 32, false>"],
     "fps N=4096 M=1024": ["epnet::pruned::fps_indexed_kernel<4, 16, false>"],
-    "group": ["epnet::group_xyz_centred_vec4_kernel", "epnet::gather_rows_lds_kernel"],
+    "group": ["epnet::group_xyz_centred_vec4_kernel", "epnet::gather_rows_lds2_kernel", "epnet::gather_rows_lds_kernel"],
     "scene_index N=16384": ["epnet::bq_index_kernel<1024, 14>"],
 }
 PMC_PROFILE = os.path.join("profiles", "r01_pmc_traffic.json")
@@ -313,9 +313,10 @@ def main():
     dominant = max(kernels, key=lambda k: kernels[k]["step_ms"])
     fps_note = ("FPS is a chain of M-1 dependent arg-max rounds per scene (latency bound, one workgroup per scene, ~0.6 us per "
                 "round): its HBM fraction is tiny by construction; see roofline_hbm_bound for the bandwidth-bound kernel")
-    grp_note = ("grouping = [grouped xyz - centre ; grouped features] of one MSG scale (epnet_group_concat; the 8 calls of a "
-                "step, 2 of them without features): random reads from LDS-staged rows, 16-byte coalesced writes; a plain "
-                "device-to-device copy on this box runs at device_copy_GBps")
+    grp_note = ("grouping = [grouped xyz - centre ; grouped features] of BOTH MSG scales of a level (epnet_group_concat_multi: one "
+                "call per level, 4 per step, the level-1 one without features; per call the centred-xyz kernel of each scale and "
+                "one row gather serving both scales): feature rows staged in LDS once, random reads from LDS, 16-byte coalesced "
+                "streaming writes; a plain device-to-device copy on this box runs at device_copy_GBps")
     roofline = roof(dominant, fps_note if dominant.startswith("fps") else grp_note)
     hbm_label = max((k for k in kernels if not k.startswith("fps")), key=lambda k: kernels[k]["step_ms"])
     roofline_hbm = roof(hbm_label, grp_note if hbm_label.startswith("group") else "")

@@ -10,9 +10,9 @@ into per-op-family tables that can be held against bench.py's own numbers.
       /opt/skills/guides/MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports half of the bytes of a
       streaming read, so hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024; WRITE_SIZE is exact.
 
-Family = one C-ABI call of the SA stack. The fused grouping call (epnet_group_concat) launches the centred-xyz
-kernel and, when the level has features, the LDS-staged row gather right after it: either way that is one "group"
-launch.
+Family = one C-ABI call of the SA stack. The grouping call of a level (epnet_group_concat_multi, both MSG scales)
+launches the centred-xyz kernel per scale and, when the level has features, the LDS-staged row gather serving both
+scales: together that is one "group" launch.
 """
 import collections
 import csv
@@ -24,7 +24,7 @@ import sys
 # kernel-name prefixes (template argument lists may continue) -> op family
 FPS = {"fps_indexed_kernel<8, 32": "fps N=16384 M=4096", "fps_indexed_kernel<4, 16": "fps N=4096 M=1024",
        "fps_pruned_kernel<8, 32": "fps N=16384 M=4096", "fps_pruned_kernel<4, 16": "fps N=4096 M=1024",
-       "fps_wave_kernel<1, 16": "fps N=1024 M=256", "fps_wave_kernel<1, 4": "fps N=256 M=64"}
+       "fps_wave_kernel<1, 16": "fps N=1024 M=256", "fps_wave_kernel<8, 2": "fps N=1024 M=256", "fps_wave_kernel<1, 4": "fps N=256 M=64"}
 
 
 def short(name):
@@ -44,17 +44,18 @@ def families(rows):
                 fam = label
         if fam is None:
             if "group_xyz_centred" in n:
-                nxt = rows[i + 1]["name"] if i + 1 < len(rows) else ""
-                if "gather_rows_lds_kernel" in nxt or "gather_rows_vec4_kernel" in nxt or "gather_rows_scalar" in nxt:
-                    fam, idx = "group", [i, i + 1]
-                else:
-                    fam = "group"   # a level without features: the centred-xyz kernel is the whole call
+                # one grouping CALL (epnet_group_concat_multi: both scales of the level) = the run of centred-xyz and row-gather
+                # kernels up to the next op: [xyz, xyz] without features, [xyz, xyz, lds2] with the rows staged once,
+                # [xyz, rows, xyz, rows] when the launch is too small for that
+                fam = "group"
+                while idx[-1] + 1 < len(rows) and ("group_xyz_centred" in rows[idx[-1] + 1]["name"] or "gather_rows" in rows[idx[-1] + 1]["name"]):
+                    idx.append(idx[-1] + 1)
             elif "gather_rows" in n:
                 fam = "gather"
             elif "bq_index_kernel" in n:
                 fam = "scene_index"
-            elif "bq_query_kernel" in n or "ball_query_kernel" in n:
-                fam = "ball_query " + re.search(r"(bq_query_kernel<[\d, ]+>|ball_query_kernel<\d+>)", n).group(1)
+            elif "bq_query_kernel" in n or "bq_query2_kernel" in n or "ball_query_kernel" in n:
+                fam = "ball_query " + re.search(r"(bq_query2?_kernel<[\d, ]+>|ball_query_kernel<\d+>)", n).group(1)
             else:
                 fam = "torch: " + n[:60]
         out.append((fam, idx))
