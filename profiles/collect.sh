@@ -31,6 +31,9 @@ python3 profiles/summarize.py pmc $F $W $BATCH $OUT/pmc_traffic.json
 cp $F $OUT/pmc_fetch_size.csv; cp $W $OUT/pmc_write_size.csv
 rm -rf $OUT/stats_default $OUT/stats_alone $OUT/pmc_fetch $OUT/pmc_write
 python3 bench_ops.py > $OUT/bench_ops.jsonl
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_ops -- python3 bench_ops.py --reps 5 > $OUT/bench_ops_under_rocprof.jsonl
+cp $(find $OUT/stats_ops -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_ops.csv
+rm -rf $OUT/stats_ops
 echo "per-op pass done"
 python3 bench.py --with-fp --cpu-scenes 0 > $OUT/bench_withfp.json
 for B in 1 16 64 128 512; do python3 bench.py --cpu-scenes 0 --batch $B --pipelined $([ $B -ge 64 ] && echo 1 || echo 0) >> $OUT/sweep.jsonl; done
