@@ -39,3 +39,8 @@ python3 bench.py --with-fp --cpu-scenes 0 > $OUT/bench_withfp.json
 for B in 1 16 64 128 512; do python3 bench.py --cpu-scenes 0 --batch $B --pipelined $([ $B -ge 64 ] && echo 1 || echo 0) >> $OUT/sweep.jsonl; done
 python3 bench.py --cpu-scenes 0 --batch 256 --pipelined 0 >> $OUT/sweep.jsonl
 echo "sweep done"
+python3 bench_step.py > $OUT/bench_step.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_step -- python3 bench_step.py --steps 5 > $OUT/bench_step_under_rocprof.json
+cp $(find $OUT/stats_step -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_step.csv
+rm -rf $OUT/stats_step
+echo "training-step pass done"
