@@ -42,6 +42,8 @@ SIGNATURES = {
     "epnet_three_interpolate_grad": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "epnet_three_interpolate_grad_workspace_bytes": (_sz, [_i, _i, _i]),
     "epnet_three_interpolate_grad_ws": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "epnet_pool_max": (_i, [ctypes.c_longlong, _i, _vp, _vp, _vp, _vp]),
+    "epnet_pool_max_grad": (_i, [ctypes.c_longlong, _i, _vp, _vp, _vp, _vp]),
     "epnet_scene_index_bytes": (_sz, [_i, _i]),
     "epnet_scene_index_build": (_i, [_i, _i, _vp, _vp, _sz, _vp]),
     "epnet_furthest_point_sampling_indexed": (_i, [_i, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp]),

@@ -294,3 +294,25 @@ def group_concat_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_fea
             _lib.check(l.epnet_group_concat_grad(b, c, n, npoints, nsample, pg, pi, pp, int(bool(use_xyz)), s),
                        "group_concat_grad")
     return 1
+
+
+def pool_max_wrapper(rows, nsample, x, out, arg):
+    """the SA level's neighbourhood max-pool (F.max_pool2d(kernel_size=[1, nsample]), pointnet2_modules.py:61-68): x
+    (rows, nsample) -> out (rows), arg (rows) int32 or None (not in the reference extension; see epnet_ops.h)"""
+    px, po = dev_ptr(x, "x", _F), dev_ptr(out, "out", _F)
+    pa = dev_ptr(arg, "arg", _I) if arg is not None else None
+    need(x, rows * nsample, "x"); need(out, rows, "out")
+    if arg is not None:
+        need(arg, rows, "arg")
+    with on_device_of(x) as s:
+        _lib.check(_lib.lib().epnet_pool_max(rows, nsample, px, po, pa, s), "pool_max")
+    return 1
+
+
+def pool_max_grad_wrapper(rows, nsample, grad_out, arg, grad_x):
+    pg, pa, px = dev_ptr(grad_out, "grad_out", _F), dev_ptr(arg, "arg", _I), dev_ptr(grad_x, "grad_x", _F)
+    need(grad_out, rows, "grad_out"); need(arg, rows, "arg"); need(grad_x, rows * nsample, "grad_x")
+    with on_device_of(grad_out) as s:
+        _lib.check(_lib.lib().epnet_pool_max_grad(rows, nsample, pg, pa, px, s), "pool_max_grad")
+    return 1
+

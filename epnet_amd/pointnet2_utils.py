@@ -297,6 +297,36 @@ def group_concat_multi(xyz, new_xyz, features, idxs, use_xyz=True):
     return list(_GroupConcatMulti.apply(xyz.contiguous(), new_xyz.contiguous(), feats, use_xyz or features is None, *idxs))
 
 
+class _PoolMax(Function):
+    """max over the last axis of a contiguous (..., nsample) tensor, keepdim -- the values of
+    F.max_pool2d(x, kernel_size=[1, nsample]) (reference pointnet2_modules.py:61-68) from a kernel that reads the rows with
+    coalesced 16-byte loads; the backward routes every gradient to the recorded position of its maximum"""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        nsample = x.shape[-1]
+        rows = x.numel() // max(nsample, 1)
+        out = _new(x, x.shape[:-1] + (1,))
+        need_grad = ctx.needs_input_grad[0]
+        arg = _new(x, x.shape[:-1], dtype=torch.int32) if need_grad else None
+        _ext.pool_max_wrapper(rows, nsample, x, out, arg)
+        ctx.for_backwards = (arg, tuple(x.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        arg, shape = ctx.for_backwards
+        grad_x = _new(grad_out, shape)
+        _ext.pool_max_grad_wrapper(grad_x.numel() // shape[-1], shape[-1], grad_out.detach().contiguous(), arg, grad_x)
+        return grad_x
+
+
+def pool_max(x):
+    """(B, C, npoint, nsample) -> (B, C, npoint, 1): the neighbourhood max-pool of an SA level"""
+    return _PoolMax.apply(x)
+
+
 class QueryAndGroup(nn.Module):
     """ball_query -> group xyz -> subtract the centre -> group features -> concat [xyz(3), features(C)].
     reference: pointnet2_utils.py:231-264. Same values as that composition; the grouped tensor is produced

@@ -151,6 +151,14 @@ int epnet_three_interpolate_grad_ws(int b, int c, int n, int m, const float *gra
                                     const float *weight, float *grad_points, void *workspace, size_t workspace_bytes,
                                     epnet_stream_t stream);
 
+/* the neighbourhood max-pool of an SA level, F.max_pool2d(kernel_size=[1, nsample]) of pointnet2_modules.py:61-68: x
+ * (rows, nsample) contiguous (rows = B * C * npoint) -> out (rows) = the row maximum (ties: lowest position; NaN
+ * propagates), arg (rows) i32 or NULL = its position for the backward. epnet_pool_max_grad: grad_x (rows, nsample) =
+ * grad_out[row] at arg[row], zero elsewhere (every element is written). */
+int epnet_pool_max(long long rows, int nsample, const float *x, float *out, int *arg, epnet_stream_t stream);
+int epnet_pool_max_grad(long long rows, int nsample, const float *grad_out, const int *arg, float *grad_x,
+                        epnet_stream_t stream);
+
 /* ----------------------------------------------------------------------------------------
  * scene index: one spatial sort of a level's points (1024 <= n <= 65536), built once in caller scratch and
  * shared by the sampling and both ball queries of that level (the reference has no counterpart: every one of

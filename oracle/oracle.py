@@ -291,3 +291,17 @@ def rpn_proposals(proposals, scores, order, distance_based, pre_nms_top_n, post_
         ret_s[k, :len(s_all)] = s_all
         count[k] = len(s_all)
     return ret_b, ret_s, count
+
+
+def pool_max(x):
+    """F.max_pool2d(x, kernel_size=[1, nsample]) of pointnet2_lib/pointnet2/pointnet2_modules.py:61-68 as numpy: maximum over
+    the last axis (keepdim) and its first position (the stock kernel scans in order with a strict `>`)."""
+    x = _f32(x)
+    return x.max(axis=-1, keepdims=True), x.argmax(axis=-1).astype(np.int32)
+
+
+def pool_max_grad(grad_out, arg, nsample):
+    g = np.zeros(arg.shape + (nsample,), np.float32)
+    np.put_along_axis(g, arg[..., None].astype(np.int64), _f32(grad_out).reshape(arg.shape + (1,)), axis=-1)
+    return g
+

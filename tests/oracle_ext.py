@@ -80,6 +80,20 @@ def make_modules():
               three_interpolate_wrapper, three_interpolate_grad_wrapper):
         setattr(p2, f.__name__, f)
 
+    def pool_max_wrapper(rows, nsample, x, out, arg):
+        v, a = oracle.pool_max(_np(x).reshape(rows, nsample))
+        wr(out, v)
+        if arg is not None:
+            wr(arg, a)
+        return 1
+
+    def pool_max_grad_wrapper(rows, nsample, grad_out, arg, grad_x):
+        wr(grad_x, oracle.pool_max_grad(_np(grad_out).reshape(rows), _np(arg).reshape(rows), nsample))
+        return 1
+
+    for f in (pool_max_wrapper, pool_max_grad_wrapper):
+        setattr(p2, f.__name__, f)
+
     iou = types.ModuleType("iou3d_cuda")
 
     def boxes_overlap_bev_gpu(a, b, ans):
