@@ -233,6 +233,148 @@ __global__ __launch_bounds__(kGThreads) void group_xyz_centred_vec4_kernel(int n
     *reinterpret_cast<float4 *>(dst + (size_t)p * 2) = make_float4(p0[2] - cz, p1[2] - cz, p2[2] - cz, p3[2] - cz);
 }
 
+// ---- first shared-MLP layer folded into the grouping -----------------------------------------
+// An SA level feeds [xyz[idx] - centre ; features[idx]] to a 1x1 convolution (pointnet2_utils.py:250-257 ->
+// pointnet2_modules.py:61). A 1x1 convolution is linear and pointwise, so it commutes with the gather of its feature
+// columns:  W . [dxyz ; F[:, idx]] = W_xyz . dxyz + (W_f . F)[:, idx].  The caller multiplies the N feature columns once
+// (z = W_f . F, a dense GEMM on N instead of npoint * nsample columns) and this kernel writes the layer's
+// pre-activations directly:
+//     out[b, co, m, s] = z[b, co, idx[b, m, s]] + (wx[co][0] * dx + wx[co][1] * dy + wx[co][2] * dz) (+ bias[co]),
+//     (dx, dy, dz) = xyz[b, idx[b, m, s]] - new_xyz[b, m]
+// (products and sums in exactly this order, no contraction). The (3 + C_in, npoint, nsample) grouped tensor is never
+// materialised, neither forwards nor for the backward. Same staging as gather_rows_lds_kernel: `rows` rows of z in LDS.
+__global__ __launch_bounds__(kGLdsThreads) void group_linear_lds_kernel(int c, int n, int npoints, int nsample, int rows, int tile,
+                                                                        const float *__restrict__ z, const float *__restrict__ xyz,
+                                                                        const float *__restrict__ new_xyz, const int *__restrict__ idx,
+                                                                        const float *__restrict__ wx, const float *__restrict__ bias,
+                                                                        float *__restrict__ out) {
+    extern __shared__ float s_rows[];
+    const int bs = blockIdx.z;
+    const int c0 = blockIdx.y * rows;
+    const int nr = min(rows, c - c0);
+    const int p = npoints * nsample;
+    const float *src = z + ((size_t)bs * c + c0) * n;
+    const int total = nr * n;
+    if ((n & 3) == 0 && ((uintptr_t)src & 15) == 0) {
+        const float4 *src4 = reinterpret_cast<const float4 *>(src);
+        float4 *dst4 = reinterpret_cast<float4 *>(s_rows);
+        for (int e = threadIdx.x; e < total / 4; e += kGLdsThreads) dst4[e] = src4[e];
+    } else {
+        for (int e = threadIdx.x; e < total; e += kGLdsThreads) s_rows[e] = src[e];
+    }
+    __syncthreads();
+    const int q_begin = blockIdx.x * tile, q_end = min(p, q_begin + tile);
+    const int *ix = idx + (size_t)bs * p;
+    const float *pts = xyz + (size_t)bs * n * 3;
+    float *dst_base = out + ((size_t)bs * c + c0) * p;
+    for (int q = q_begin + threadIdx.x * 4; q < q_end; q += kGLdsThreads * 4) {
+        const int4 id = *reinterpret_cast<const int4 *>(ix + q);
+        const float *ce = new_xyz + ((size_t)bs * npoints + q / nsample) * 3;  // nsample % 4 == 0: one centre per thread
+        const float cx = ce[0], cy = ce[1], cz = ce[2];
+        const float *p0 = pts + (size_t)id.x * 3, *p1 = pts + (size_t)id.y * 3, *p2 = pts + (size_t)id.z * 3, *p3 = pts + (size_t)id.w * 3;
+        const float dx0 = p0[0] - cx, dy0 = p0[1] - cy, dz0 = p0[2] - cz;
+        const float dx1 = p1[0] - cx, dy1 = p1[1] - cy, dz1 = p1[2] - cz;
+        const float dx2 = p2[0] - cx, dy2 = p2[1] - cy, dz2 = p2[2] - cz;
+        const float dx3 = p3[0] - cx, dy3 = p3[1] - cy, dz3 = p3[2] - cz;
+        float *dst = dst_base + q;
+        const float *row = s_rows;
+#pragma unroll 2
+        for (int r = 0; r < nr; ++r) {
+            const float w0 = wx[(c0 + r) * 3], w1 = wx[(c0 + r) * 3 + 1], w2 = wx[(c0 + r) * 3 + 2];  // wave-uniform
+            float4 v;
+            v.x = row[id.x] + (w0 * dx0 + w1 * dy0 + w2 * dz0);
+            v.y = row[id.y] + (w0 * dx1 + w1 * dy1 + w2 * dz1);
+            v.z = row[id.z] + (w0 * dx2 + w1 * dy2 + w2 * dz2);
+            v.w = row[id.w] + (w0 * dx3 + w1 * dy3 + w2 * dz3);
+            if (bias) {
+                const float bv = bias[c0 + r];
+                v.x += bv; v.y += bv; v.z += bv; v.w += bv;
+            }
+            store_stream(dst, v.x, v.y, v.z, v.w);
+            row += n;
+            dst += p;
+        }
+    }
+}
+
+// any shape: one thread per position, kGChan channels per block row, z read through L1 / L2
+__global__ __launch_bounds__(kGThreads) void group_linear_scalar_kernel(int c, int n, int npoints, int nsample,
+                                                                        const float *__restrict__ z, const float *__restrict__ xyz,
+                                                                        const float *__restrict__ new_xyz, const int *__restrict__ idx,
+                                                                        const float *__restrict__ wx, const float *__restrict__ bias,
+                                                                        float *__restrict__ out) {
+    const int bs = blockIdx.z;
+    const int c0 = blockIdx.y * kGChan;
+    const int p = npoints * nsample;
+    const int q = blockIdx.x * kGThreads + threadIdx.x;
+    if (q >= p) return;
+    const int id = idx[(size_t)bs * p + q];
+    const float *pt = xyz + ((size_t)bs * n + id) * 3;
+    const float *ce = new_xyz + ((size_t)bs * npoints + q / nsample) * 3;
+    const float dx = pt[0] - ce[0], dy = pt[1] - ce[1], dz = pt[2] - ce[2];
+    const int cend = min(c, c0 + kGChan);
+    for (int ci = c0; ci < cend; ++ci) {
+        float v = z[((size_t)bs * c + ci) * n + id] + (wx[ci * 3] * dx + wx[ci * 3 + 1] * dy + wx[ci * 3 + 2] * dz);
+        if (bias) v += bias[ci];
+        out[((size_t)bs * c + ci) * p + q] = v;
+    }
+}
+
+// gradient of group_linear w.r.t. w_xyz: grad_w[co][k] += sum over (b, m, s) of grad_out[b,co,m,s] * (xyz[b,idx] - new_xyz[b,m])[k].
+// The centred coordinates are rebuilt per position (never stored); a block owns kGwRows channel rows x a tile of positions
+// of one scene, every thread keeps kGwRows x 3 partial sums, reduced by shuffles + LDS and added to grad_w with 3 * kGwRows
+// float atomics per block (a dense-product formulation has K = b * npoint * nsample and 3 output columns: rocBLAS takes
+// 4.4 ms for the 537 MB of the RCNN stage's first level; this kernel reads them once).
+constexpr int kGwRows = 8;
+__global__ __launch_bounds__(kGThreads) void group_linear_grad_w_kernel(int c, int n, int npoints, int nsample, int tile,
+                                                                        const float *__restrict__ grad_out,
+                                                                        const float *__restrict__ xyz,
+                                                                        const float *__restrict__ new_xyz,
+                                                                        const int *__restrict__ idx, float *__restrict__ grad_w) {
+    __shared__ float s_part[kGThreads / 64][kGwRows * 3];
+    const int bs = blockIdx.z;
+    const int c0 = blockIdx.y * kGwRows;
+    const int nr = min(kGwRows, c - c0);
+    const int p = npoints * nsample;
+    const int q_begin = blockIdx.x * tile, q_end = min(p, q_begin + tile);
+    const int *ix = idx + (size_t)bs * p;
+    const float *pts = xyz + (size_t)bs * n * 3;
+    const float *g = grad_out + ((size_t)bs * c + c0) * p;
+    float acc[kGwRows][3];
+#pragma unroll
+    for (int r = 0; r < kGwRows; ++r) acc[r][0] = acc[r][1] = acc[r][2] = 0.f;
+    for (int q = q_begin + threadIdx.x; q < q_end; q += kGThreads) {
+        const int id = ix[q];
+        const float *pt = pts + (size_t)id * 3;
+        const float *ce = new_xyz + ((size_t)bs * npoints + q / nsample) * 3;
+        const float dx = pt[0] - ce[0], dy = pt[1] - ce[1], dz = pt[2] - ce[2];
+#pragma unroll
+        for (int r = 0; r < kGwRows; ++r) {
+            if (r < nr) {
+                const float gv = g[(size_t)r * p + q];
+                acc[r][0] += gv * dx;
+                acc[r][1] += gv * dy;
+                acc[r][2] += gv * dz;
+            }
+        }
+    }
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < kGwRows; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float v = wave_sum_f32(acc[r][k]);
+            if (lane == 0) s_part[wave][r * 3 + k] = v;
+        }
+    __syncthreads();
+    if (threadIdx.x < nr * 3) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < kGThreads / 64; ++w) v += s_part[w][threadIdx.x];
+        atomicAdd(grad_w + (size_t)c0 * 3 + threadIdx.x, v);
+    }
+}
+
 static int launch_gather_rows(int b, int c, int n, long long p, const float *points, const int *idx, float *out,
                               hipStream_t s, const char *what, size_t ostride = 0) {
     if (ostride == 0) ostride = (size_t)c * (size_t)p;
@@ -607,3 +749,57 @@ extern "C" int epnet_group_concat_grad_ws(int b, int c, int n, int npoints, int 
     return launch_scatter_rows_csr(b, c, n, p, grad_out + (size_t)ch0 * p, idx, grad_features, workspace, workspace_bytes,
                                    (hipStream_t)stream, "group_concat_grad", gstride);
 }
+
+extern "C" int epnet_group_linear(int b, int c, int n, int npoints, int nsample, const float *xyz, const float *new_xyz,
+                                  const float *z, const int *idx, const float *w_xyz, const float *bias, float *out,
+                                  epnet_stream_t stream) {
+    EPNET_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0 && nsample >= 0);
+    const long long p = (long long)npoints * nsample;
+    if (b == 0 || c == 0 || p == 0) return EPNET_OK;
+    EPNET_REQUIRE(xyz && new_xyz && z && idx && w_xyz && out && n > 0);
+    if (p > 0x7fffffffll || b > 65535 || div_up(c, kGChan) > 65535) return EPNET_ELIMIT;
+    hipStream_t s = (hipStream_t)stream;
+    constexpr int kLdsBudget = 64 * 1024;
+    const bool vec = nsample % 4 == 0 && (((uintptr_t)idx | (uintptr_t)out) % 16 == 0);
+    if (vec && c >= 8 && (size_t)n * 4 <= (size_t)kLdsBudget && p >= 1024) {
+        int rows = kLdsBudget / (n * 4);
+        if (rows > c) rows = c;
+        if (rows > 32) rows = 32;
+        const int chunks = div_up(c, rows);
+        int tiles = div_up(1024, b * chunks);  // enough workgroups to fill the chip, tiles of at least 1024 positions
+        const int max_tiles = (int)(p / 1024);
+        if (tiles > max_tiles) tiles = max_tiles;
+        if (tiles < 1) tiles = 1;
+        int tile = (int)div_up64(p, tiles);
+        tile = (tile + kGLdsThreads * 4 - 1) / (kGLdsThreads * 4) * (kGLdsThreads * 4);
+        tiles = (int)div_up64(p, tile);
+        if (chunks <= 65535) {
+            hipLaunchKernelGGL(group_linear_lds_kernel, dim3(tiles, chunks, b), dim3(kGLdsThreads), (size_t)rows * n * 4, s, c, n, npoints,
+                               nsample, rows, tile, z, xyz, new_xyz, idx, w_xyz, bias, out);
+            return check_launch("group_linear");
+        }
+    }
+    hipLaunchKernelGGL(group_linear_scalar_kernel, dim3((unsigned)div_up64(p, kGThreads), div_up(c, kGChan), b), dim3(kGThreads), 0, s, c,
+                       n, npoints, nsample, z, xyz, new_xyz, idx, w_xyz, bias, out);
+    return check_launch("group_linear");
+}
+
+extern "C" int epnet_group_linear_grad_w(int b, int c, int n, int npoints, int nsample, const float *grad_out, const float *xyz,
+                                         const float *new_xyz, const int *idx, float *grad_w, epnet_stream_t stream) {
+    EPNET_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0 && nsample >= 0);
+    const long long p = (long long)npoints * nsample;
+    if (b == 0 || c == 0 || p == 0) return EPNET_OK;
+    EPNET_REQUIRE(grad_out && xyz && new_xyz && idx && grad_w && n > 0);
+    const int chunks = div_up(c, kGwRows);
+    if (p > 0x7fffffffll || b > 65535 || chunks > 65535) return EPNET_ELIMIT;
+    int tiles = div_up(2048, b * chunks);
+    const int max_tiles = (int)div_up64(p, 1024);
+    if (tiles > max_tiles) tiles = max_tiles;
+    if (tiles < 1) tiles = 1;
+    const int tile = (int)div_up64(p, tiles);
+    tiles = (int)div_up64(p, tile);
+    hipLaunchKernelGGL(group_linear_grad_w_kernel, dim3(tiles, chunks, b), dim3(kGThreads), 0, (hipStream_t)stream, c, n, npoints,
+                       nsample, tile, grad_out, xyz, new_xyz, idx, grad_w);
+    return check_launch("group_linear_grad_w");
+}
+

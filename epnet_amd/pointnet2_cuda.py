@@ -316,3 +316,30 @@ def pool_max_grad_wrapper(rows, nsample, grad_out, arg, grad_x):
         _lib.check(_lib.lib().epnet_pool_max_grad(rows, nsample, pg, pa, px, s), "pool_max_grad")
     return 1
 
+
+def group_linear_wrapper(b, c, n, npoints, nsample, xyz, new_xyz, z, idx, w_xyz, bias, out):
+    """the first shared-MLP layer of an SA level folded into its grouping: out (b,c,npoints,nsample) =
+    z[:, :, idx] + w_xyz . (xyz[idx] - centre) (+ bias); z (b,c,n) = W_f . features (not in the reference extension; see
+    epnet_ops.h)"""
+    px, pn, pz = dev_ptr(xyz, "xyz", _F), dev_ptr(new_xyz, "new_xyz", _F), dev_ptr(z, "z", _F)
+    pi, pw, po = dev_ptr(idx, "idx", _I), dev_ptr(w_xyz, "w_xyz", _F), dev_ptr(out, "out", _F)
+    pb = dev_ptr(bias, "bias", _F) if bias is not None else None
+    need(xyz, b * n * 3, "xyz"); need(new_xyz, b * npoints * 3, "new_xyz"); need(z, b * c * n, "z")
+    need(idx, b * npoints * nsample, "idx"); need(w_xyz, c * 3, "w_xyz"); need(out, b * c * npoints * nsample, "out")
+    if bias is not None:
+        need(bias, c, "bias")
+    with on_device_of(z) as s:
+        _lib.check(_lib.lib().epnet_group_linear(b, c, n, npoints, nsample, px, pn, pz, pi, pw, pb, po, s), "group_linear")
+    return 1
+
+
+def group_linear_grad_w_wrapper(b, c, n, npoints, nsample, grad_out, xyz, new_xyz, idx, grad_w):
+    """grad_w (c,3), zero-filled by the caller, += sum of grad_out[b,co,m,s] * (xyz[idx] - centre)[k]"""
+    pg, px, pn = dev_ptr(grad_out, "grad_out", _F), dev_ptr(xyz, "xyz", _F), dev_ptr(new_xyz, "new_xyz", _F)
+    pi, pw = dev_ptr(idx, "idx", _I), dev_ptr(grad_w, "grad_w", _F)
+    need(grad_out, b * c * npoints * nsample, "grad_out"); need(xyz, b * n * 3, "xyz"); need(new_xyz, b * npoints * 3, "new_xyz")
+    need(idx, b * npoints * nsample, "idx"); need(grad_w, c * 3, "grad_w")
+    with on_device_of(grad_out) as s:
+        _lib.check(_lib.lib().epnet_group_linear_grad_w(b, c, n, npoints, nsample, pg, px, pn, pi, pw, s), "group_linear_grad_w")
+    return 1
+

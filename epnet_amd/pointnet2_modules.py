@@ -4,9 +4,11 @@ Same public classes, constructor keywords, return values and ``state_dict`` key 
 reference's pointnet2_lib/pointnet2/pointnet2_modules.py (``_PointnetSAModuleBase``:10,
 ``PointnetSAModuleMSG``:75, ``PointnetSAModule``:112, ``PointnetFPModule``:133), so lib/net's
 ``Pointnet2MSG`` / ``RCNNNet`` build on it unchanged and reference checkpoints load. The geometry
-ops (FPS, gather, ball query, grouping, three_nn, three_interpolate) run on the HIP kernels; the
-shared MLPs and the pooling stay on stock PyTorch-ROCm.
+ops (FPS, gather, ball query, grouping, three_nn, three_interpolate) and the neighbourhood max-pool run on
+the HIP kernels; the shared MLPs stay on stock PyTorch-ROCm, the first 1x1 convolution of a level being applied to
+the N points before the grouping instead of to the npoint * nsample grouped columns after it.
 """
+import os
 from typing import List, Optional
 
 import torch
@@ -17,6 +19,22 @@ from . import pointnet2_utils
 from . import pytorch_utils as pt_utils
 
 
+def _foldable(grouper, mlp, features) -> bool:
+    """can the first layer of `mlp` be folded into the grouping? A ball-query grouper that prepends xyz, features present,
+    and a first unit that starts with a plain 1x1 convolution over [xyz(3) ; features(C)]"""
+    if not isinstance(grouper, pointnet2_utils.QueryAndGroup) or not grouper.use_xyz or features is None:
+        return False
+    if features.dtype != torch.float32 or len(mlp) == 0:
+        return False
+    first = mlp[0]
+    children = list(first.children())
+    conv = getattr(first, "conv", None)
+    if not isinstance(conv, nn.Conv2d) or not children or children[0] is not conv:   # pre-activated units start with bn / act
+        return False
+    return (conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1
+            and conv.in_channels == features.shape[1] + 3)
+
+
 class _PointnetSAModuleBase(nn.Module):
     def __init__(self):
         super().__init__()
@@ -24,6 +42,9 @@ class _PointnetSAModuleBase(nn.Module):
         self.groupers = None
         self.mlps = None
         self.pool_method = 'max_pool'
+        # fold the first 1x1 convolution of every scale into its grouping (EPNET_SA_FOLD_FIRST_LAYER=0: build the grouped
+        # tensor and convolve it, as the reference does)
+        self.fold_first_layer = os.environ.get("EPNET_SA_FOLD_FIRST_LAYER", "1") != "0"
 
     def _pool(self, x: torch.Tensor) -> torch.Tensor:
         window = [1, x.size(3)]
@@ -55,12 +76,32 @@ class _PointnetSAModuleBase(nn.Module):
         if index is not None and len(self.groupers) > 1 and all(isinstance(g, pointnet2_utils.QueryAndGroup) for g in self.groupers):
             idxs = pointnet2_utils.ball_query_multi([g.radius for g in self.groupers], [g.nsample for g in self.groupers],
                                                     xyz, new_xyz.contiguous(), index)
+        # first 1x1 convolution folded into the grouping (pointnet2_utils.group_linear): W . [dxyz ; F[:, idx]] =
+        # W_xyz . dxyz + (W_f . F)[:, idx] -- the dense product runs over the N points instead of npoint * nsample columns
+        # and the (3 + C, npoint, nsample) grouped tensor is never built
+        coords_need_grad = torch.is_grad_enabled() and (xyz.requires_grad or (new_xyz is not None and new_xyz.requires_grad))
+        foldable = [self.fold_first_layer and not coords_need_grad and _foldable(g, m, features)
+                    for g, m in zip(self.groupers, self.mlps)]
         groups = None
-        if (idxs is not None and len({g.use_xyz for g in self.groupers}) == 1 and features is not None
-                and not (torch.is_grad_enabled() and (xyz.requires_grad or new_xyz.requires_grad))):
+        if (idxs is not None and len({g.use_xyz for g in self.groupers}) == 1 and features is not None and not any(foldable)
+                and not coords_need_grad):
             groups = pointnet2_utils.group_concat_multi(xyz, new_xyz, features, idxs, self.groupers[0].use_xyz)
         pooled = []
         for k, (grouper, mlp) in enumerate(zip(self.groupers, self.mlps)):
+            if foldable[k]:
+                nidx = idxs[k] if idxs is not None else pointnet2_utils.ball_query(grouper.radius, grouper.nsample, xyz,
+                                                                                 new_xyz.contiguous(), index)
+                conv = mlp[0].conv
+                w = conv.weight[:, :, 0, 0]
+                z = torch.matmul(w[:, 3:], features)            # (B, C_out, N)
+                hidden = pointnet2_utils.group_linear(xyz, new_xyz, z, nidx, w[:, :3], conv.bias)
+                for name, layer in mlp[0].named_children():     # what follows the convolution inside the first unit
+                    if layer is not conv:
+                        hidden = layer(hidden)
+                for layer in list(mlp.children())[1:]:
+                    hidden = layer(hidden)
+                pooled.append(self._pool(hidden).squeeze(-1))
+                continue
             if groups is not None:
                 grouped = groups[k]
             elif idxs is not None:

@@ -297,6 +297,45 @@ def group_concat_multi(xyz, new_xyz, features, idxs, use_xyz=True):
     return list(_GroupConcatMulti.apply(xyz.contiguous(), new_xyz.contiguous(), feats, use_xyz or features is None, *idxs))
 
 
+class _GroupLinear(Function):
+    """pre-activations of an SA level's first 1x1 convolution without the grouped tensor:
+    out = z[:, :, idx] + w_xyz . (xyz[idx] - new_xyz) (+ bias), z = W_f . features computed by the caller on the N points.
+    Equals conv(cat(grouped xyz - centre, grouped features)) of the reference (pointnet2_utils.py:250-257 +
+    pointnet2_modules.py:61) up to the summation order of the dense product."""
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, z, idx, w_xyz, bias):
+        b, c, n = z.shape
+        npoint, nsample = idx.shape[1], idx.shape[2]
+        out = _new(z, (b, c, npoint, nsample))
+        _ext.group_linear_wrapper(b, c, n, npoint, nsample, xyz, new_xyz, z, idx, w_xyz, bias, out)
+        ctx.save_for_backward(xyz, new_xyz, idx)
+        ctx.dims = (b, c, n, npoint, nsample, bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        xyz, new_xyz, idx = ctx.saved_tensors
+        b, c, n, npoint, nsample, has_bias = ctx.dims
+        g = grad_out.detach().contiguous()
+        grad_z = grad_w = grad_b = None
+        if ctx.needs_input_grad[2]:      # scatter-add over the neighbour lists, as for any grouped tensor
+            grad_z = _new(g, (b, c, n), zero=True)
+            _ext.group_points_grad_wrapper(b, c, n, npoint, nsample, g, idx, grad_z)
+        if ctx.needs_input_grad[4]:      # d out / d w_xyz = the centred neighbour coordinates, rebuilt inside the reduction
+            grad_w = _new(g, (c, 3), zero=True)
+            _ext.group_linear_grad_w_wrapper(b, c, n, npoint, nsample, g, xyz, new_xyz, idx, grad_w)
+        if has_bias and ctx.needs_input_grad[5]:
+            grad_b = g.sum(dim=(0, 2, 3))
+        return None, None, grad_z, None, grad_w, grad_b
+
+
+def group_linear(xyz, new_xyz, z, idx, w_xyz, bias=None):
+    """(B,N,3), (B,M,3), z (B,C,N), idx (B,M,ns) int32, w_xyz (C,3), bias (C) -> (B,C,M,ns)"""
+    return _GroupLinear.apply(xyz.contiguous(), new_xyz.contiguous(), z.contiguous(), idx, w_xyz.contiguous(),
+                              None if bias is None else bias.contiguous())
+
+
 class _PoolMax(Function):
     """max over the last axis of a contiguous (..., nsample) tensor, keepdim -- the values of
     F.max_pool2d(x, kernel_size=[1, nsample]) (reference pointnet2_modules.py:61-68) from a kernel that reads the rows with

@@ -151,6 +151,22 @@ int epnet_three_interpolate_grad_ws(int b, int c, int n, int m, const float *gra
                                     const float *weight, float *grad_points, void *workspace, size_t workspace_bytes,
                                     epnet_stream_t stream);
 
+/* The first shared-MLP layer of an SA level folded into its grouping. The reference materialises
+ * [xyz[idx] - centre ; features[idx]] (pointnet2_utils.py:250-257) and runs a 1x1 convolution W over it
+ * (pointnet2_modules.py:61); that convolution is linear and pointwise, so W . [dxyz ; F[:, idx]] =
+ * W_xyz . dxyz + (W_f . F)[:, idx]. With z = W_f . F (b, c, n) computed by the caller (a dense GEMM over n columns instead of
+ * npoints * nsample), this writes the layer's pre-activations out (b, c, npoints, nsample):
+ *   out[b,co,m,s] = z[b,co,idx[b,m,s]] + (w_xyz[co][0]*dx + w_xyz[co][1]*dy + w_xyz[co][2]*dz) (+ bias[co]),
+ *   (dx,dy,dz) = xyz[b,idx[b,m,s]] - new_xyz[b,m]; w_xyz (c,3), bias (c) or NULL. */
+int epnet_group_linear(int b, int c, int n, int npoints, int nsample, const float *xyz, const float *new_xyz, const float *z,
+                       const int *idx, const float *w_xyz, const float *bias, float *out, epnet_stream_t stream);
+
+/* gradient of epnet_group_linear w.r.t. w_xyz: grad_w (c,3) += sum over (b,m,s) of grad_out[b,co,m,s] * (xyz[b,idx[b,m,s]] -
+ * new_xyz[b,m])[k]; the caller zero-fills grad_w (accumulated with float atomics: summation order unspecified). The gradient
+ * w.r.t. z is epnet_group_points_grad of grad_out, the one w.r.t. bias its sum over (b,m,s). */
+int epnet_group_linear_grad_w(int b, int c, int n, int npoints, int nsample, const float *grad_out, const float *xyz,
+                              const float *new_xyz, const int *idx, float *grad_w, epnet_stream_t stream);
+
 /* the neighbourhood max-pool of an SA level, F.max_pool2d(kernel_size=[1, nsample]) of pointnet2_modules.py:61-68: x
  * (rows, nsample) contiguous (rows = B * C * npoint) -> out (rows) = the row maximum (ties: lowest position; NaN
  * propagates), arg (rows) i32 or NULL = its position for the backward. epnet_pool_max_grad: grad_x (rows, nsample) =

@@ -305,3 +305,24 @@ def pool_max_grad(grad_out, arg, nsample):
     np.put_along_axis(g, arg[..., None].astype(np.int64), _f32(grad_out).reshape(arg.shape + (1,)), axis=-1)
     return g
 
+
+def group_linear(xyz, new_xyz, z, idx, w_xyz, bias=None):
+    """epnet_group_linear: out[b,co,m,s] = z[b,co,idx[b,m,s]] + (w[co,0]*dx + w[co,1]*dy + w[co,2]*dz) (+ bias[co]) with
+    (dx,dy,dz) = xyz[b,idx[b,m,s]] - new_xyz[b,m], fp32 products and sums in this order. It is the first 1x1 convolution
+    of an SA level (pointnet2_modules.py:61) applied to [grouped xyz - centre ; grouped features] (pointnet2_utils.py:250-257)
+    with the feature part of the product, z = W_f . features, taken before the gather."""
+    xyz, new_xyz, z, w = _f32(xyz), _f32(new_xyz), _f32(z), _f32(w_xyz)
+    b, c, n = z.shape
+    m, ns = idx.shape[1], idx.shape[2]
+    out = np.empty((b, c, m, ns), np.float32)
+    for bi in range(b):
+        d = (xyz[bi][idx[bi]] - new_xyz[bi][:, None, :]).astype(np.float32)          # (m, ns, 3)
+        t = (w[:, None, None, 0] * d[None, :, :, 0]).astype(np.float32)
+        t = (t + (w[:, None, None, 1] * d[None, :, :, 1]).astype(np.float32)).astype(np.float32)
+        t = (t + (w[:, None, None, 2] * d[None, :, :, 2]).astype(np.float32)).astype(np.float32)
+        v = (z[bi][:, idx[bi]] + t).astype(np.float32)
+        if bias is not None:
+            v = (v + _f32(bias)[:, None, None]).astype(np.float32)
+        out[bi] = v
+    return out
+

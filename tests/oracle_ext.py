@@ -91,7 +91,16 @@ def make_modules():
         wr(grad_x, oracle.pool_max_grad(_np(grad_out).reshape(rows), _np(arg).reshape(rows), nsample))
         return 1
 
-    for f in (pool_max_wrapper, pool_max_grad_wrapper):
+    def group_linear_wrapper(b, c, n, npoints, nsample, xyz, new_xyz, z, idx, w_xyz, bias, out):
+        wr(out, oracle.group_linear(_np(xyz), _np(new_xyz), _np(z), _np(idx), _np(w_xyz), None if bias is None else _np(bias)))
+        return 1
+
+    def group_linear_grad_w_wrapper(b, c, n, npoints, nsample, grad_out, xyz, new_xyz, idx, grad_w):
+        d = _np(xyz)[np.arange(b)[:, None, None], _np(idx).astype(np.int64)] - _np(new_xyz)[:, :, None, :]      # (b,m,ns,3)
+        wr(grad_w, _np(grad_w) + np.einsum("bcms,bmsk->ck", _np(grad_out).astype(np.float64), d.astype(np.float64)).astype(np.float32))
+        return 1
+
+    for f in (pool_max_wrapper, pool_max_grad_wrapper, group_linear_wrapper, group_linear_grad_w_wrapper):
         setattr(p2, f.__name__, f)
 
     iou = types.ModuleType("iou3d_cuda")
