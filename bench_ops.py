@@ -155,6 +155,16 @@ def main():
                bsz * (n * 28 + n * 4 + n * 8 + mcfg.RPN_POST_NMS_TOP_N * 32),
                "sort + bin compaction + batched NMS + gather, no host sync; per-scene host loop on the same NMS kernels: %.3f ms "
                "(same result: %s); box decoding (stock tensor ops): %.3f ms" % (ms_host, same, ms_dec))
+    # ---- LI-Fusion point-to-pixel sampler: the image pyramid of the yaml (LI_FUSION.IMG_CHANNELS) at 2 scenes
+    import torch.nn.functional as F
+    from epnet_amd.li_fusion import Feature_Gather
+    for (c, h, w, n) in ((64, 192, 640, 4096), (128, 96, 320, 1024), (256, 48, 160, 256), (512, 24, 80, 64), (32, 384, 1280, 16384)):
+        fmap = torch.randn((2, c, h, w), generator=g).to(dev)
+        xy = (torch.rand((2, n, 2), generator=g) * 2 - 1).to(dev)
+        ms_stock = timeit(lambda: F.grid_sample(fmap, xy.unsqueeze(1), mode="bilinear", padding_mode="zeros", align_corners=True))
+        ms = timeit(lambda: Feature_Gather(fmap, xy))
+        report("Feature_Gather", {"B": 2, "C": c, "H": h, "W": w, "N": n}, ms, 2 * (n * 8 + c * n * 4 * 4 + c * n * 4),
+               "bytes = 4 taps read + 1 value written per (point, channel); stock grid_sample: %.4f ms" % ms_stock)
     # ---- roipool3d: (B,16384,3)+(B,16384,130) -> (B,64,512,133)
     for bsz, m in ((2, 64), (1, 100), (16, 64)):
         pts = synth.scenes("kitti", bsz, 16384, seed=5).to(dev)

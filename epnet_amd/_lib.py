@@ -44,6 +44,8 @@ SIGNATURES = {
     "epnet_three_interpolate_grad_ws": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "epnet_group_linear": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "epnet_group_linear_grad_w": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "epnet_feature_gather": (_i, [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "epnet_feature_gather_grad": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "epnet_pool_max": (_i, [ctypes.c_longlong, _i, _vp, _vp, _vp, _vp]),
     "epnet_pool_max_grad": (_i, [ctypes.c_longlong, _i, _vp, _vp, _vp, _vp]),
     "epnet_scene_index_bytes": (_sz, [_i, _i]),

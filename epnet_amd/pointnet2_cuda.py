@@ -343,3 +343,28 @@ def group_linear_grad_w_wrapper(b, c, n, npoints, nsample, grad_out, xyz, new_xy
         _lib.check(_lib.lib().epnet_group_linear_grad_w(b, c, n, npoints, nsample, pg, px, pn, pi, pw, s), "group_linear_grad_w")
     return 1
 
+
+def feature_gather_wrapper(b, c, h, w, n_src, n, align_corners, feature_map, xy, idx, out, xy_out):
+    """LI-Fusion's point-to-pixel bilinear sampler (lib/net/pointnet2_msg.py:107-120) with the xy gather over the FPS
+    indices folded in (not in the reference extension; see epnet_ops.h)"""
+    pf, px, po = dev_ptr(feature_map, "feature_map", _F), dev_ptr(xy, "xy", _F), dev_ptr(out, "out", _F)
+    pi = dev_ptr(idx, "idx", _I) if idx is not None else None
+    pxo = dev_ptr(xy_out, "xy_out", _F) if xy_out is not None else None
+    need(feature_map, b * c * h * w, "feature_map"); need(xy, b * n_src * 2, "xy"); need(out, b * c * n, "out")
+    if idx is not None:
+        need(idx, b * n, "idx")
+    if xy_out is not None:
+        need(xy_out, b * n * 2, "xy_out")
+    with on_device_of(feature_map) as s:
+        _lib.check(_lib.lib().epnet_feature_gather(b, c, h, w, n_src, n, int(bool(align_corners)), pf, px, pi, po, pxo, s),
+                   "feature_gather")
+    return 1
+
+
+def feature_gather_grad_wrapper(b, c, h, w, n, align_corners, grad_out, xy, grad_feature_map):
+    pg, px, pf = dev_ptr(grad_out, "grad_out", _F), dev_ptr(xy, "xy", _F), dev_ptr(grad_feature_map, "grad_feature_map", _F)
+    need(grad_out, b * c * n, "grad_out"); need(xy, b * n * 2, "xy"); need(grad_feature_map, b * c * h * w, "grad_feature_map")
+    with on_device_of(grad_out) as s:
+        _lib.check(_lib.lib().epnet_feature_gather_grad(b, c, h, w, n, int(bool(align_corners)), pg, px, pf, s), "feature_gather_grad")
+    return 1
+

@@ -175,6 +175,18 @@ int epnet_pool_max(long long rows, int nsample, const float *x, float *out, int 
 int epnet_pool_max_grad(long long rows, int nsample, const float *grad_out, const int *arg, float *grad_x,
                         epnet_stream_t stream);
 
+/* LI-Fusion's point-to-pixel sampler: Feature_Gather of lib/net/pointnet2_msg.py:107-120 =
+ * torch grid_sample(feature_map (b,c,h,w), xy (b,1,n,2) in [-1,1]) -> out (b,c,n), bilinear, zero padding, with the
+ * torch.gather of xy over the FPS indices (:214-217) folded in: idx (b,n) i32 or NULL picks the rows of xy (b,n_src,2)
+ * (NULL: n_src == n, row q of xy), xy_out (b,n,2) or NULL receives the picked coordinates for the next level.
+ * align_corners as in torch (the reference was written for torch <= 1.2, where grid_sample behaved as align_corners=True).
+ * epnet_feature_gather_grad: grad_feature_map (b,c,h,w), zero-filled by the caller, += the bilinear scatter of grad_out
+ * (b,c,n) at xy (b,n,2) (float atomics). */
+int epnet_feature_gather(int b, int c, int h, int w, int n_src, int n, int align_corners, const float *feature_map,
+                         const float *xy, const int *idx, float *out, float *xy_out, epnet_stream_t stream);
+int epnet_feature_gather_grad(int b, int c, int h, int w, int n, int align_corners, const float *grad_out, const float *xy,
+                              float *grad_feature_map, epnet_stream_t stream);
+
 /* ----------------------------------------------------------------------------------------
  * scene index: one spatial sort of a level's points (1024 <= n <= 65536), built once in caller scratch and
  * shared by the sampling and both ball queries of that level (the reference has no counterpart: every one of

@@ -100,7 +100,24 @@ def make_modules():
         wr(grad_w, _np(grad_w) + np.einsum("bcms,bmsk->ck", _np(grad_out).astype(np.float64), d.astype(np.float64)).astype(np.float32))
         return 1
 
-    for f in (pool_max_wrapper, pool_max_grad_wrapper, group_linear_wrapper, group_linear_grad_w_wrapper):
+    def feature_gather_wrapper(b, c, h, w, n_src, n, align_corners, feature_map, xy, idx, out, xy_out):
+        # the op the reference calls (lib/net/pointnet2_msg.py:107-120) is stock torch: it is its own CPU yardstick
+        import torch.nn.functional as F
+        sel = xy if idx is None else torch.gather(xy, 1, idx.long().unsqueeze(-1).repeat(1, 1, 2))
+        out.copy_(F.grid_sample(feature_map, sel.unsqueeze(1), mode="bilinear", padding_mode="zeros", align_corners=bool(align_corners)).squeeze(2))
+        if xy_out is not None:
+            xy_out.copy_(sel)
+        return 1
+
+    def feature_gather_grad_wrapper(b, c, h, w, n, align_corners, grad_out, xy, grad_feature_map):
+        import torch.nn.functional as F
+        fm = torch.zeros((b, c, h, w), requires_grad=True)
+        F.grid_sample(fm, xy.unsqueeze(1), mode="bilinear", padding_mode="zeros", align_corners=bool(align_corners)).squeeze(2).backward(grad_out)
+        grad_feature_map.add_(fm.grad)
+        return 1
+
+    for f in (pool_max_wrapper, pool_max_grad_wrapper, group_linear_wrapper, group_linear_grad_w_wrapper, feature_gather_wrapper,
+              feature_gather_grad_wrapper):
         setattr(p2, f.__name__, f)
 
     iou = types.ModuleType("iou3d_cuda")
