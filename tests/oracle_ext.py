@@ -111,8 +111,9 @@ def make_modules():
 
     def feature_gather_grad_wrapper(b, c, h, w, n, align_corners, grad_out, xy, grad_feature_map):
         import torch.nn.functional as F
-        fm = torch.zeros((b, c, h, w), requires_grad=True)
-        F.grid_sample(fm, xy.unsqueeze(1), mode="bilinear", padding_mode="zeros", align_corners=bool(align_corners)).squeeze(2).backward(grad_out)
+        with torch.enable_grad():   # called from inside an autograd backward, where recording is off
+            fm = torch.zeros((b, c, h, w), requires_grad=True)
+            F.grid_sample(fm, xy.unsqueeze(1), mode="bilinear", padding_mode="zeros", align_corners=bool(align_corners)).squeeze(2).backward(grad_out)
         grad_feature_map.add_(fm.grad)
         return 1
 
