@@ -102,33 +102,39 @@ def build_model(scale=1, rpn_channels=76):
             self.rpn_cls = nn.Sequential(pt_utils.Conv1d(128, 128, bn=True), pt_utils.Conv1d(128, 1, activation=None))
             self.rpn_reg = nn.Sequential(pt_utils.Conv1d(128, 128, bn=True), pt_utils.Conv1d(128, rpn_channels, activation=None))
             self.rcnn = RCNN()
+            self.layers = None   # (ProposalLayer, ProposalTargetLayer), set by the caller
+
+        def forward(self, xyz, gt_boxes3d, mark=None):
+            """one forward pass + placeholder loss (the whole step lives in forward so that DistributedDataParallel sees
+            it); returns (loss, dict of outputs)"""
+            proposal_layer, target_layer = self.layers
+            mark = mark if mark is not None else (lambda name: None)
+            feats = self.backbone(xyz)                                           # (B,128,N)
+            rpn_cls = self.rpn_cls(feats).transpose(1, 2).contiguous()           # (B,N,1)
+            rpn_reg = self.rpn_reg(feats).transpose(1, 2).contiguous()           # (B,N,76)
+            mark("rpn")
+            with torch.no_grad():                                                # lib/net/point_rcnn.py:33-47
+                scores = rpn_cls[:, :, 0].detach()
+                rois, _ = proposal_layer(scores, rpn_reg.detach(), xyz)
+                mark("proposals")
+                seg_mask = (torch.sigmoid(scores) > 0.3).float()
+                depth = torch.norm(xyz, p=2, dim=2)
+                target = target_layer({"roi_boxes3d": rois, "gt_boxes3d": gt_boxes3d, "rpn_xyz": xyz,
+                                       "rpn_features": feats.detach().permute(0, 2, 1).contiguous(), "seg_mask": seg_mask,
+                                       "pts_depth": depth})
+                mark("targets")
+            rcnn_cls, rcnn_reg = self.rcnn(target["sampled_pts"], target["pts_feature"])
+            mark("rcnn")
+            loss = rpn_cls.pow(2).mean() + rpn_reg.pow(2).mean() + rcnn_cls.pow(2).mean() + rcnn_reg.pow(2).mean()
+            return loss, {"rois": rois, "target": target, "rcnn_cls": rcnn_cls, "rcnn_reg": rcnn_reg}
 
     return TwoStage()
 
 
 def run_step(model, layers, xyz, gt_boxes3d, timer=None):
-    """one forward pass + placeholder loss; returns (loss, dict of outputs)"""
-    import torch
-    proposal_layer, target_layer = layers
-    mark = timer if timer is not None else (lambda name: None)
-    m = model.module if hasattr(model, "module") else model
-    feats = m.backbone(xyz)                                              # (B,128,N)
-    rpn_cls = m.rpn_cls(feats).transpose(1, 2).contiguous()              # (B,N,1)
-    rpn_reg = m.rpn_reg(feats).transpose(1, 2).contiguous()              # (B,N,76)
-    mark("rpn")
-    with torch.no_grad():                                                # lib/net/point_rcnn.py:33-47
-        scores = rpn_cls[:, :, 0].detach()
-        rois, _ = proposal_layer(scores, rpn_reg.detach(), xyz)
-        mark("proposals")
-        seg_mask = (torch.sigmoid(scores) > 0.3).float()
-        depth = torch.norm(xyz, p=2, dim=2)
-        target = target_layer({"roi_boxes3d": rois, "gt_boxes3d": gt_boxes3d, "rpn_xyz": xyz,
-                               "rpn_features": feats.detach().permute(0, 2, 1).contiguous(), "seg_mask": seg_mask, "pts_depth": depth})
-        mark("targets")
-    rcnn_cls, rcnn_reg = m.rcnn(target["sampled_pts"], target["pts_feature"])
-    mark("rcnn")
-    loss = rpn_cls.pow(2).mean() + rpn_reg.pow(2).mean() + rcnn_cls.pow(2).mean() + rcnn_reg.pow(2).mean()
-    return loss, {"rois": rois, "target": target, "rcnn_cls": rcnn_cls, "rcnn_reg": rcnn_reg}
+    """one forward pass through `model` (plain or DistributedDataParallel-wrapped)"""
+    (model.module if hasattr(model, "module") else model).layers = layers
+    return model(xyz, gt_boxes3d, timer)
 
 
 def synthetic_batch(batch, points, seed, device):
@@ -154,10 +160,16 @@ def main():
     from epnet_amd import proposal_layer as pl, proposal_target_layer as ptl
 
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    # EPNET_BENCH_DEVICE / EPNET_BENCH_BACKEND rehearse the N > 1 path on a one-GPU box (all ranks on one device, gloo)
+    local = int(os.environ.get("EPNET_BENCH_DEVICE", local))
+    backend = os.environ.get("EPNET_BENCH_BACKEND", "nccl")
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     torch.manual_seed(1 + rank)
     np.random.seed(1 + rank)
     model = build_model().to(device)
