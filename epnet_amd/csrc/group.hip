@@ -73,6 +73,13 @@ __global__ __launch_bounds__(kGThreads) void gather_rows_scalar_kernel(int c, in
 #ifndef EPNET_GATHER_LDS_THREADS
 #define EPNET_GATHER_LDS_THREADS 256
 #endif
+// rows in flight per thread in the serving loop (4 LDS reads each). Alone on the device the kernel does not care (1: 5.07-5.22,
+// 4: 5.11-5.22 TB/s), but in the software-pipelined SA stack it shares every CU with the sampling kernels, whose rounds wait
+// on four dependent LDS operations: the fewer gather reads queue in front of those, the shorter the round. 256-scene step:
+// unroll 8 4.10, 4 3.97, 2 3.86, 1 3.82 ms
+#ifndef EPNET_GATHER_LDS_UNROLL
+#define EPNET_GATHER_LDS_UNROLL 1
+#endif
 constexpr int kGLdsThreads = EPNET_GATHER_LDS_THREADS;
 __global__ __launch_bounds__(kGLdsThreads) void gather_rows_lds_kernel(int c, int n, int p, int rows, int tile, size_t ostride,
                                                                     const float *__restrict__ points,
@@ -99,7 +106,7 @@ __global__ __launch_bounds__(kGLdsThreads) void gather_rows_lds_kernel(int c, in
         const int4 id = *reinterpret_cast<const int4 *>(ix + q);
         float *dst = dst_base + q;
         const float *row = s_rows;
-#pragma unroll 4
+#pragma unroll EPNET_GATHER_LDS_UNROLL
         for (int r = 0; r < nr; ++r) {
             float4 v;
             v.x = row[id.x];
@@ -113,6 +120,9 @@ __global__ __launch_bounds__(kGLdsThreads) void gather_rows_lds_kernel(int c, in
     }
 }
 
+#ifndef EPNET_GATHER_LDS2_UNROLL
+#define EPNET_GATHER_LDS2_UNROLL 1   // see EPNET_GATHER_LDS_UNROLL
+#endif
 // the same for the TWO scales of an MSG level at once: both gather from the same feature rows, so the rows are
 // staged once and then serve both index sets (saves one 64 KB staging pass per workgroup: 7-12 % of the traffic)
 __global__ __launch_bounds__(kGLdsThreads) void gather_rows_lds2_kernel(int c, int n, int rows, const float *__restrict__ points,
@@ -142,7 +152,7 @@ __global__ __launch_bounds__(kGLdsThreads) void gather_rows_lds2_kernel(int c, i
             const int4 id = *reinterpret_cast<const int4 *>(ix + q);
             float *dst = dst_base + q;
             const float *row = s_rows;
-#pragma unroll 4
+#pragma unroll EPNET_GATHER_LDS2_UNROLL
             for (int r = 0; r < nr; ++r) {
                 float4 v;
                 v.x = row[id.x];
