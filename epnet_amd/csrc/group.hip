@@ -70,6 +70,16 @@ __global__ __launch_bounds__(kGThreads) void gather_rows_scalar_kernel(int c, in
 // instruction, and the kernel runs at the rate of its 16-byte coalesced stores. Measured on random
 // indices (C=96, N=4096, P=32768, B=64): direct gather 1.9 TB/s, this kernel see profiles/.
 // grid: (tiles, row chunks, scenes); dynamic LDS: R * n floats; p % 4 == 0.
+#ifndef EPNET_GATHER_STAGE_UNROLL
+#define EPNET_STAGE_PRAGMA
+#else
+#define EPNET_STAGE_STR2(x) #x
+#define EPNET_STAGE_STR(x) EPNET_STAGE_STR2(unroll x)
+#define EPNET_STAGE_PRAGMA _Pragma(EPNET_STAGE_STR(EPNET_GATHER_STAGE_UNROLL))
+#endif
+#ifndef EPNET_GATHER_LDS_BUDGET_KB
+#define EPNET_GATHER_LDS_BUDGET_KB 64   // LDS per row-gather workgroup: two workgroups per CU (32: 3.91, 128: 4.63 ms per 256-scene step against 3.78)
+#endif
 #ifndef EPNET_GATHER_LDS_THREADS
 #define EPNET_GATHER_LDS_THREADS 256
 #endif
@@ -94,6 +104,7 @@ __global__ __launch_bounds__(kGLdsThreads) void gather_rows_lds_kernel(int c, in
     if ((n & 3) == 0 && ((uintptr_t)src & 15) == 0) {
         const float4 *src4 = reinterpret_cast<const float4 *>(src);
         float4 *dst4 = reinterpret_cast<float4 *>(s_rows);
+        EPNET_STAGE_PRAGMA
         for (int e = threadIdx.x; e < total / 4; e += kGLdsThreads) dst4[e] = src4[e];
     } else {
         for (int e = threadIdx.x; e < total; e += kGLdsThreads) s_rows[e] = src[e];
@@ -138,6 +149,7 @@ __global__ __launch_bounds__(kGLdsThreads) void gather_rows_lds2_kernel(int c, i
     if ((n & 3) == 0 && ((uintptr_t)src & 15) == 0) {
         const float4 *src4 = reinterpret_cast<const float4 *>(src);
         float4 *dst4 = reinterpret_cast<float4 *>(s_rows);
+        EPNET_STAGE_PRAGMA
         for (int e = threadIdx.x; e < total / 4; e += kGLdsThreads) dst4[e] = src4[e];
     } else {
         for (int e = threadIdx.x; e < total; e += kGLdsThreads) s_rows[e] = src[e];
@@ -268,6 +280,7 @@ __global__ __launch_bounds__(kGLdsThreads) void group_linear_lds_kernel(int c, i
     if ((n & 3) == 0 && ((uintptr_t)src & 15) == 0) {
         const float4 *src4 = reinterpret_cast<const float4 *>(src);
         float4 *dst4 = reinterpret_cast<float4 *>(s_rows);
+        EPNET_STAGE_PRAGMA
         for (int e = threadIdx.x; e < total / 4; e += kGLdsThreads) dst4[e] = src4[e];
     } else {
         for (int e = threadIdx.x; e < total; e += kGLdsThreads) s_rows[e] = src[e];
@@ -392,7 +405,7 @@ static int launch_gather_rows(int b, int c, int n, long long p, const float *poi
     if (!(points && idx && out)) return EPNET_EINVAL;
     if (p > 0x7fffffffll || b > 65535 || div_up(c, kGChan) > 65535) return EPNET_ELIMIT;
     const bool vec = (p % 4 == 0) && (((uintptr_t)idx | (uintptr_t)out) % 16 == 0);
-    constexpr int kLdsBudget = 64 * 1024;  // two workgroups per CU
+    constexpr int kLdsBudget = EPNET_GATHER_LDS_BUDGET_KB * 1024;  // two workgroups per CU
     if (vec && c >= 8 && (size_t)n * 4 <= kLdsBudget && p >= 2048) {  // few channels (xyz): the rows stay in L2 anyway
         int rows = kLdsBudget / (n * 4);
         if (rows > c) rows = c;
@@ -594,7 +607,7 @@ static int launch_scatter_rows(int b, int c, int n, long long p, const float *gr
     if (b == 0 || c == 0 || p == 0 || n == 0) return EPNET_OK;
     if (!(grad_out && idx && grad_points)) return EPNET_EINVAL;
     if (p > 0x7fffffffll || b > 65535) return EPNET_ELIMIT;
-    constexpr int kLdsBudget = 64 * 1024;  // two workgroups per CU
+    constexpr int kLdsBudget = EPNET_GATHER_LDS_BUDGET_KB * 1024;  // two workgroups per CU
     if ((size_t)n * 4 <= kLdsBudget) {
         int rows = kLdsBudget / (n * 4);
         if (rows > 8) rows = 8;
@@ -675,7 +688,7 @@ extern "C" int epnet_group_concat_multi(int b, int c, int n, int npoints, int ns
     EPNET_REQUIRE(nscales >= 0 && (nscales == 0 || (nsamples && idx && out)));
     hipStream_t s = (hipStream_t)stream;
     const int ch0 = use_xyz ? 3 : 0;
-    constexpr int kLdsBudget = 64 * 1024;
+    constexpr int kLdsBudget = EPNET_GATHER_LDS_BUDGET_KB * 1024;
     bool fused = nscales == 2 && c >= 8 && b > 0 && npoints > 0 && (size_t)n * 4 <= (size_t)kLdsBudget && features && b <= 65535;
     int rows = 0;
     if (fused) {
@@ -769,7 +782,7 @@ extern "C" int epnet_group_linear(int b, int c, int n, int npoints, int nsample,
     EPNET_REQUIRE(xyz && new_xyz && z && idx && w_xyz && out && n > 0);
     if (p > 0x7fffffffll || b > 65535 || div_up(c, kGChan) > 65535) return EPNET_ELIMIT;
     hipStream_t s = (hipStream_t)stream;
-    constexpr int kLdsBudget = 64 * 1024;
+    constexpr int kLdsBudget = EPNET_GATHER_LDS_BUDGET_KB * 1024;
     const bool vec = nsample % 4 == 0 && (((uintptr_t)idx | (uintptr_t)out) % 16 == 0);
     if (vec && c >= 8 && (size_t)n * 4 <= (size_t)kLdsBudget && p >= 1024) {
         int rows = kLdsBudget / (n * 4);
