@@ -151,8 +151,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=2, help="scenes per GPU (16 over 8 GPUs in config 4)")
     ap.add_argument("--points", type=int, default=16384)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -207,9 +207,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    last = None
+    last, per_step = None, []
     for _ in range(args.steps):
+        t_step = time.perf_counter()
         last = one(True)
+        per_step.append(time.perf_counter() - t_step)      # one(True) ends with a device synchronisation
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -223,6 +225,8 @@ def main():
         print(json.dumps({"metric": "rcnn_online point-stream training step (BASELINE config 4, per-rank part)", "n_gpus": world,
                           "scenes_per_gpu": args.batch, "points_per_scene": args.points, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+                          "ms_per_step_median": round(sorted(per_step)[len(per_step) // 2] * 1e3, 3),
+                          "ms_per_step_max": round(max(per_step) * 1e3, 3),
                           "scenes_per_s": round(world * args.batch * args.steps / elapsed, 2),
                           "phase_ms": {k: round(v / args.steps, 3) for k, v in phases.items()},
                           "parameters": n_param, "grad_allreduce_MB": round(n_param * 4 / 1e6, 1) if world > 1 else 0,
