@@ -36,7 +36,15 @@ __device__ __forceinline__ Taps taps_of(float x, float y, int h, int w, int alig
         ix = ((x + 1.f) * (float)w - 1.f) / 2.f;
         iy = ((y + 1.f) * (float)h - 1.f) / 2.f;
     }
-    const float fx = floorf(ix), fy = floorf(iy);
+    float fx = floorf(ix), fy = floorf(iy);
+    // a tap can only be inside the map for -1 <= floor <= size - 1; anything else (far outside, infinite, NaN) is moved to
+    // a corner that has no in-bounds tap, so that the int conversion below is always defined
+    if (!(fx >= -1.f && fx <= (float)(w - 1) && fy >= -1.f && fy <= (float)(h - 1))) {
+        fx = -2.f;
+        fy = -2.f;
+        ix = -2.f;
+        iy = -2.f;
+    }
     Taps t;
     t.x0 = (int)fx;
     t.y0 = (int)fy;

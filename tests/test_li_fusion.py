@@ -41,6 +41,21 @@ def test_feature_gather_equals_grid_sample(hiplib, b, c, h, w, n, align):
 
 
 @pytest.mark.gpu
+def test_feature_gather_far_outside_and_non_finite_coordinates(hiplib):
+    """points projected far outside the image, at infinity or NaN sample nothing: zeros (grid_sample's zero padding),
+    and they scatter nothing in the backward"""
+    from epnet_amd.li_fusion import Feature_Gather
+    fmap = torch.randn((1, 3, 5, 7)).cuda().requires_grad_(True)
+    xy = torch.tensor([[[0.0, 0.0], [50.0, 0.0], [0.0, -1e30], [float("inf"), 0.0], [float("nan"), 0.2], [0.3, float("nan")], [-1.0, 1.0]]]).cuda()
+    out = Feature_Gather(fmap, xy)
+    assert torch.equal(out[0, :, 1:6], torch.zeros((3, 5), device="cuda"))
+    want = F.grid_sample(fmap.detach(), xy[:, [0, 6]].unsqueeze(1), mode="bilinear", padding_mode="zeros", align_corners=True).squeeze(2)
+    torch.testing.assert_close(out[:, :, [0, 6]].detach(), want, rtol=1e-5, atol=1e-6)
+    out[:, :, 1:6].sum().backward()
+    assert float(fmap.grad.abs().sum()) == 0.0
+
+
+@pytest.mark.gpu
 def test_feature_gather_with_fps_indices(hiplib):
     """the reference's two steps -- torch.gather of xy over the FPS indices, then the sampler (:214-218) -- in one call"""
     from epnet_amd.li_fusion import Feature_Gather
