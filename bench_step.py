@@ -43,8 +43,9 @@ def build_model(scale=1, rpn_channels=76):
     """the two-stage point model; scale > 1 divides the pyramid's point counts (small test configurations)"""
     import torch
     import torch.nn as nn
-    from epnet_amd import pytorch_utils as pt_utils
+    from epnet_amd import pointnet2_utils as p2u, pytorch_utils as pt_utils
     from epnet_amd.pointnet2_modules import PointnetFPModule, PointnetSAModule, PointnetSAModuleMSG
+    PYRAMID = os.environ.get("EPNET_SA_PYRAMID", "1") != "0"
 
     class Backbone(nn.Module):   # lib/net/pointnet2_msg.py:126-196, 201-232 without the image branch
         def __init__(self):
@@ -63,8 +64,10 @@ def build_model(scale=1, rpn_channels=76):
 
         def forward(self, xyz):
             l_xyz, l_feat = [xyz], [None]
-            for sa in self.SA_modules:
-                nx, nf, _ = sa(l_xyz[-1], l_feat[-1])
+            # every level's sampling up front on a side stream: it runs beside the MLPs instead of between them
+            pyramid = p2u.sample_pyramid(xyz, [sa.npoint for sa in self.SA_modules]) if PYRAMID else [None] * len(self.SA_modules)
+            for sa, pre in zip(self.SA_modules, pyramid):
+                nx, nf, _ = sa(l_xyz[-1], l_feat[-1], presampled=pre)
                 l_xyz.append(nx)
                 l_feat.append(nf)
             for i in range(-1, -(len(self.FP_modules) + 1), -1):
@@ -147,12 +150,53 @@ def synthetic_batch(batch, points, seed, device):
     return xyz, gts.to(device)
 
 
+def infer(args, model, proposal_layer, xyz):
+    """RPN-stage inference latency: eager launches against one HIP-graph replay"""
+    import torch
+    model.eval()
+
+    def stage():
+        with torch.no_grad():
+            feats = model.backbone(xyz)
+            cls = model.rpn_cls(feats).transpose(1, 2).contiguous()
+            reg = model.rpn_reg(feats).transpose(1, 2).contiguous()
+            return proposal_layer(cls[:, :, 0].contiguous(), reg, xyz)
+
+    def timed(fn, reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(max(3, args.warmup)):
+            eager_out = stage()
+    torch.cuda.current_stream().wait_stream(side)
+    ms_eager = timed(stage, args.steps)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        graph_out = stage()
+    graph.replay()
+    torch.cuda.synchronize()
+    same = all(torch.equal(a, b) for a, b in zip(eager_out, graph_out))
+    ms_graph = timed(graph.replay, args.steps)
+    print(json.dumps({"metric": "RPN-stage inference latency (backbone + heads + proposal layer, eval mode)", "scenes": args.batch,
+                      "points_per_scene": args.points, "ms_eager": round(ms_eager, 3), "ms_hip_graph": round(ms_graph, 3),
+                      "graph_equals_eager": bool(same), "dtype": "f32", "data": "synthetic"}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=2, help="scenes per GPU (16 over 8 GPUs in config 4)")
     ap.add_argument("--points", type=int, default=16384)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--infer", action="store_true",
+                    help="instead of the training step: inference latency of the RPN stage (backbone, heads, proposal layer) in "
+                         "eval mode, eagerly and replayed from a HIP graph (nothing in the stage synchronises with the host)")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -178,6 +222,9 @@ def main():
     opt = torch.optim.SGD(model.parameters(), lr=1e-4, momentum=0.9)
     layers = (pl.ProposalLayer("TRAIN").to(device), ptl.ProposalTargetLayer())
     xyz, gts = synthetic_batch(args.batch, args.points, 100 + 1000 * rank, device)   # every rank its own scenes
+
+    if args.infer:
+        return infer(args, model.module if hasattr(model, "module") else model, layers[0], xyz)
 
     phases = {}
 

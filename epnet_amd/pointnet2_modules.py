@@ -56,11 +56,15 @@ class _PointnetSAModuleBase(nn.Module):
             return F.avg_pool2d(x, kernel_size=window)
         raise NotImplementedError
 
-    def forward(self, xyz: torch.Tensor, features: Optional[torch.Tensor] = None, new_xyz=None):
+    def forward(self, xyz: torch.Tensor, features: Optional[torch.Tensor] = None, new_xyz=None, presampled=None):
         """xyz (B,N,3), features (B,C,N) -> (new_xyz (B,npoint,3), new_features (B,sum mlp[-1],npoint),
         idx (B,npoint) int32 FPS indices or None). The 3-tuple (reference :72) is what
         lib/net/pointnet2_msg.py:214-218 unpacks; LI-Fusion consumes idx."""
         idx = None
+        if presampled is not None:   # (idx, new_xyz, event) of pointnet2_utils.sample_pyramid: the level's sampling, done up front
+            idx, new_xyz, ready = presampled
+            assert new_xyz.shape[1] == self.npoint
+            torch.cuda.current_stream(xyz.device).wait_event(ready)
         # one spatial sort of the level's points serves the sampling and every ball query of the level
         index = pointnet2_utils.scene_index(xyz) if self.npoint is not None and xyz.is_cuda else None
         if new_xyz is None and self.npoint is not None:

@@ -49,7 +49,20 @@ class FurthestPointSampling(Function):
 furthest_point_sample = FurthestPointSampling.apply
 
 
-_INDEX_CACHE = {}  # id(tensor) -> (weakref, tensor._version, index): the SA level's index is found again by its FP module
+_INDEX_CACHE = {}  # id(tensor) -> (weakref, tensor._version, index, capture epoch): the SA level's index is found again by its FP module
+_CAPTURE = {"epoch": 0, "was_capturing": False}
+
+
+def _capture_epoch() -> int:
+    """0 outside HIP-graph capture, a fresh positive number for every capture. A graph replay rewrites tensors without
+    touching their version counters, so an index remembered eagerly must not be baked into a graph (the graph would keep
+    using the index of the capture-time coordinates), and one built inside a capture says nothing about the tensor's
+    content afterwards: remembered indices are only valid within the capture (or the eager stretch) that built them."""
+    capturing = torch.cuda.is_current_stream_capturing() if torch.cuda.is_available() else False
+    if capturing and not _CAPTURE["was_capturing"]:
+        _CAPTURE["epoch"] += 1
+    _CAPTURE["was_capturing"] = capturing
+    return _CAPTURE["epoch"] if capturing else 0
 
 
 def scene_index(xyz: torch.Tensor, cached_only: bool = False) -> Optional[torch.Tensor]:
@@ -61,8 +74,9 @@ def scene_index(xyz: torch.Tensor, cached_only: bool = False) -> Optional[torch.
     if not xyz.is_cuda or not xyz.is_contiguous():
         return None
     key = id(xyz)
+    epoch = _capture_epoch()
     hit = _INDEX_CACHE.get(key)
-    if hit is not None and hit[0]() is xyz and hit[1] == xyz._version:
+    if hit is not None and hit[0]() is xyz and hit[1] == xyz._version and hit[3] == epoch:
         return hit[2]
     if cached_only:
         return None
@@ -70,7 +84,7 @@ def scene_index(xyz: torch.Tensor, cached_only: bool = False) -> Optional[torch.
     if index is not None:
         if len(_INDEX_CACHE) > 64:
             _INDEX_CACHE.clear()
-        _INDEX_CACHE[key] = (weakref.ref(xyz, lambda _r, _k=key: _INDEX_CACHE.pop(_k, None)), xyz._version, index)
+        _INDEX_CACHE[key] = (weakref.ref(xyz, lambda _r, _k=key: _INDEX_CACHE.pop(_k, None)), xyz._version, index, epoch)
     return index
 
 
@@ -85,6 +99,40 @@ def sample_and_gather(xyz: torch.Tensor, npoint: int, index: Optional[torch.Tens
     new_xyz = _new(xyz, (batch, npoint, 3))
     _ext.sample_centres_wrapper(batch, n, npoint, xyz.detach(), index, idx, new_xyz)
     return idx, new_xyz
+
+
+_PYRAMID_STREAMS = {}
+
+
+def sample_pyramid(xyz: torch.Tensor, npoints):
+    """the sampling of ALL set-abstraction levels up front: furthest point sampling depends on the
+    coordinates only (pointnet2_modules.py:39-45), never on features, so the chain xyz -> npoints[0] -> npoints[1] -> ...
+    (scene index, FPS, centres of every level) is issued on a side stream and runs beside the shared MLPs of the levels
+    above it instead of between them. Returns one ``(idx, new_xyz, event)`` per level for
+    ``_PointnetSAModuleBase.forward(..., presampled=...)``, which waits for the event; same values as the modules
+    compute themselves."""
+    assert xyz.is_cuda and xyz.is_contiguous()
+    dev = xyz.device
+    main = torch.cuda.current_stream(dev)
+    side = _PYRAMID_STREAMS.get(dev.index)
+    if side is None:
+        side = _PYRAMID_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
+    side.wait_stream(main)
+    levels = []
+    with torch.cuda.stream(side):
+        cur = xyz.detach()
+        for k, m in enumerate(npoints):
+            src = xyz if k == 0 else cur          # the tensor object the SA module of this level will receive
+            index = scene_index(src)
+            idx, new_xyz = sample_and_gather(src, int(m), index)
+            event = torch.cuda.Event()
+            event.record(side)
+            for t in (idx, new_xyz, index):       # allocated on the side stream, consumed on the caller's
+                if t is not None:
+                    t.record_stream(main)
+            levels.append((idx, new_xyz, event))
+            cur = new_xyz
+    return levels
 
 
 class GatherOperation(Function):

@@ -107,3 +107,28 @@ def test_group_linear_gradients_equal_the_composition(hiplib, b, c, n, m, ns, bi
     torch.testing.assert_close(out.detach().cpu().double(), ref.detach(), rtol=1e-5, atol=1e-5)
     for got, exp in zip(grads, want):
         torch.testing.assert_close(got.cpu().double(), exp, rtol=1e-4, atol=1e-4 * float(exp.abs().max()) + 1e-6)
+
+
+@pytest.mark.gpu
+def test_sampling_pyramid_gives_the_modules_their_own_results(hiplib):
+    """pointnet2_utils.sample_pyramid (all levels' FPS on a side stream, up front) + presampled SA modules == the same
+    modules sampling for themselves: identical indices, centres and features"""
+    from epnet_amd import pointnet2_modules as p2m, pointnet2_utils as p2u, synth
+    torch.manual_seed(2)
+    sas = [p2m.PointnetSAModuleMSG(npoint=1024, radii=[0.5, 1.0], nsamples=[16, 32], mlps=[[0, 16, 32], [0, 16, 32]]).cuda().eval(),
+           p2m.PointnetSAModuleMSG(npoint=256, radii=[1.0, 2.0], nsamples=[16, 32], mlps=[[64, 32, 64], [64, 32, 64]]).cuda().eval(),
+           p2m.PointnetSAModuleMSG(npoint=64, radii=[2.0, 4.0], nsamples=[16, 32], mlps=[[128, 64, 64], [128, 64, 64]]).cuda().eval()]
+    xyz = synth.scenes("kitti", 2, 8192, seed=8).cuda()
+
+    def run(use_pyramid):
+        pyr = p2u.sample_pyramid(xyz, [sa.npoint for sa in sas]) if use_pyramid else [None] * 3
+        cur, feats, outs = xyz, None, []
+        with torch.no_grad():
+            for sa, pre in zip(sas, pyr):
+                cur, feats, idx = sa(cur, feats, presampled=pre)
+                outs.append((cur, feats, idx))
+        torch.cuda.synchronize()
+        return outs
+    a, b = run(True), run(False)
+    for (x1, f1, i1), (x2, f2, i2) in zip(a, b):
+        assert torch.equal(i1, i2) and torch.equal(x1, x2) and torch.equal(f1, f2)

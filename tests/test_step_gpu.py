@@ -35,3 +35,45 @@ def test_rcnn_online_step_forward_backward(hiplib):
     # the gradient reaches the first SA level of the backbone through FP modules, grouping and interpolation
     first = next(p for n, p in model.named_parameters() if n.startswith("backbone.SA_modules.0") and n.endswith("conv.weight"))
     assert float(first.grad.abs().sum()) > 0
+
+
+@pytest.mark.gpu
+def test_rpn_stage_records_into_a_hip_graph(hiplib):
+    """backbone (sampling pyramid on a side stream, SA / FP modules with folded first layers and the pool kernel), heads and
+    proposal layer in eval mode: nothing synchronises with the host, so the stage captures into a HIP graph whose replay
+    reproduces the eager outputs, also on new input coordinates"""
+    import bench_step
+    from epnet_amd import proposal_layer as pl, synth
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = bench_step.build_model(scale=8).to(dev).eval()
+    layer = pl.ProposalLayer("TEST").to(dev)
+    xyz = synth.scenes("kitti", 1, 2048, seed=3).to(dev)
+
+    def stage():
+        with torch.no_grad():
+            feats = model.backbone(xyz)
+            cls = model.rpn_cls(feats).transpose(1, 2).contiguous()
+            reg = model.rpn_reg(feats).transpose(1, 2).contiguous()
+            return proposal_layer_out(cls, reg)
+
+    def proposal_layer_out(cls, reg):
+        return layer(cls[:, :, 0].contiguous(), reg, xyz)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            eager = stage()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        captured = stage()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(eager, captured))
+    xyz.copy_(synth.scenes("kitti", 1, 2048, seed=4).to(dev))
+    graph.replay()
+    torch.cuda.synchronize()
+    fresh = stage()
+    assert all(torch.equal(a, b) for a, b in zip(fresh, captured)) and not torch.equal(fresh[0], eager[0])
