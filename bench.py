@@ -51,9 +51,11 @@ def parse():
                          "(bandwidth-bound) ball query + grouping of step k-1, double-buffered; 0: every step alone")
     ap.add_argument("--unfused", action="store_true", help="grouping as two group_points calls instead of group_concat")
     ap.add_argument("--no-shared-index", action="store_true", help="every op sorts the scene for itself")
-    ap.add_argument("--fused-sampling", action="store_true",
-                    help="epnet_sample_centres (FPS + gather of the centres in one kernel) instead of the reference module's "
-                         "sequence FPS, transpose, gather, transpose")
+    ap.add_argument("--fused-sampling", action="store_true", help="(default; kept for old command lines)")
+    ap.add_argument("--module-sampling", action="store_true",
+                    help="sample every level with the reference module's op-by-op sequence (transpose, fill temp, FPS, gather on the "
+                         "flipped cloud, transpose back: pointnet2_modules.py:30-45) instead of epnet_sample_centres (FPS + row gather "
+                         "of the centres, same idx / new_xyz): 6 instead of 3 launches per level on the sampling chain")
     ap.add_argument("--with-fp", action="store_true", help="also run the 4 three_nn + 4 three_interpolate FP ops")
     ap.add_argument("--cpu-scenes", type=int, default=int(os.environ.get("EPNET_BENCH_CPU_SCENES", "16")),
                     help="scenes in the cpu_baseline sample (0 = skip)")
@@ -261,7 +263,7 @@ def main():
         stack = sa_stack.SAStack(batch, n=args.points, device=dev, with_fp=args.with_fp, seed=rank,
                                  overlap=not args.no_overlap, fused=not args.unfused,
                                  shared_index=not args.no_shared_index, pipelined=bool(args.pipelined),
-                                 fused_sampling=args.fused_sampling)
+                                 fused_sampling=not args.module_sampling)
         if args.no_graph:
             step = lambda: stack.step(xyz)
         else:

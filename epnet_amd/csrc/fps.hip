@@ -1003,9 +1003,13 @@ static int fps_over_index(int b, int n, int m, const float *xyz, const void *ind
                                (const float *)(sorted + (size_t)b * np), temp, idx);
         } else {
             static const int wide = getenv("EPNET_FPS_WIDE") ? atoi(getenv("EPNET_FPS_WIDE")) : 0;
+            // the centres can come out of the sampling kernel itself (kCtr: the round's winner is in registers anyway) or from a
+            // small gather afterwards. In-kernel costs wave 0 an LDS write per round and 12 KB more LDS: 1.7 % on one scene,
+            // 5 % in the software-pipelined stack -- more than the extra launch, so the separate gather is the default
+            static const bool ctr_in_kernel = getenv("EPNET_FPS_CTR") && atoi(getenv("EPNET_FPS_CTR")) != 0;
 #define EPNET_FPS_INDEXED(W_, P_)                                                                                          \
     do {                                                                                                                   \
-        if (new_xyz)                                                                                                       \
+        if (new_xyz && ctr_in_kernel)                                                                                      \
             hipLaunchKernelGGL((pruned::fps_indexed_kernel<W_, P_, true>), grid, dim3(64 * W_), 0, s, n, m, sorted, temp, \
                                idx, new_xyz);                                                                              \
         else                                                                                                               \
@@ -1022,7 +1026,7 @@ static int fps_over_index(int b, int n, int m, const float *xyz, const void *ind
                     break;
             }
 #undef EPNET_FPS_INDEXED
-            centres_done = new_xyz != nullptr;
+            centres_done = new_xyz != nullptr && ctr_in_kernel;
         }
         rc = check_launch("furthest_point_sampling");
     }

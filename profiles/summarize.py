@@ -50,7 +50,7 @@ def families(rows):
                 fam = "group"
                 while idx[-1] + 1 < len(rows) and ("group_xyz_centred" in rows[idx[-1] + 1]["name"] or "gather_rows" in rows[idx[-1] + 1]["name"]):
                     idx.append(idx[-1] + 1)
-            elif "gather_rows" in n:
+            elif "gather_rows" in n or "gather_centres" in n:
                 fam = "gather"
             elif "bq_index_kernel" in n:
                 fam = "scene_index"
