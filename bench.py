@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--cpu-scenes", type=int, default=int(os.environ.get("EPNET_BENCH_CPU_SCENES", "16")),
                     help="scenes in the cpu_baseline sample (0 = skip)")
     ap.add_argument("--sweep", default="", help="comma list of extra batch sizes to time (reported under 'sweep')")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rehearse the N-rank launch only: the ranks rendezvous (backend EPNET_BENCH_BACKEND, default nccl), "
+                         "count themselves with an all-reduce and rank 0 prints n_gpus / ranks_seen; no kernels of the path")
     return ap.parse_args()
 
 
@@ -224,12 +227,39 @@ def pmc_traffic(family, args):
     return None if k is None else int(k["hbm_bytes_avg"] / prof["scenes_per_launch"] * args.batch)
 
 
+def launch_check(args):
+    """--launch-check: what the N-rank launch built, without touching the GPU (tests/test_bench_launch.py runs it on gloo)"""
+    import torch.distributed as dist
+    from epnet_amd import scene_shard
+    rank, local, world = scene_shard.env_world()
+    backend, device = os.environ.get("EPNET_BENCH_BACKEND", "nccl"), "cpu"
+    if world > 1:
+        if backend == "nccl":   # RCCL counts the ranks: one device per rank
+            import torch
+            device = torch.device("cuda", int(os.environ.get("EPNET_BENCH_DEVICE", local)))
+            torch.cuda.set_device(device)
+        scene_shard.init_process_group(backend, device=None if device == "cpu" else device)
+    seen = int(scene_shard.sum_over_ranks(1.0, device=device))
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_seen": seen, "gpus_flag": args.gpus}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    # --gpus N without a torch.distributed.run environment: start the N ranks as child processes BEFORE this process
+    # touches the GPU (it never does), and leave with their exit code
+    from epnet_amd import scene_shard
+    code = scene_shard.launch_or_continue(args.gpus, os.path.abspath(__file__), sys.argv[1:])
+    if code is not None:
+        sys.exit(code)
+    scene_shard.assert_world(args.gpus)
+    if args.launch_check:
+        return launch_check(args)
     import torch
     import torch.distributed as dist
 
-    from epnet_amd import scene_shard
     rank, local_rank, world = scene_shard.env_world()
     # CPU baselines first: the multi-core one forks workers, which must happen before this process touches the GPU
     cpu = cpu_multi = None

@@ -197,7 +197,18 @@ def main():
     ap.add_argument("--infer", action="store_true",
                     help="instead of the training step: inference latency of the RPN stage (backbone, heads, proposal layer) in "
                          "eval mode, eagerly and replayed from a HIP graph (nothing in the stage synchronises with the host)")
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="ranks (one per GPU); without a torch.distributed.run environment the ranks are started as child processes")
+    ap.add_argument("--launch-check", action="store_true", help="rehearse the N-rank launch only (see bench.py)")
     args = ap.parse_args()
+    from epnet_amd import scene_shard
+    code = scene_shard.launch_or_continue(args.gpus, os.path.abspath(__file__), sys.argv[1:])
+    if code is not None:
+        sys.exit(code)
+    scene_shard.assert_world(args.gpus)
+    if args.launch_check:
+        import bench
+        return bench.launch_check(args)
     import numpy as np
     import torch
     import torch.distributed as dist

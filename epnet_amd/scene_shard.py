@@ -16,6 +16,61 @@ def env_world():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+def launch_plan(gpus, script, argv, environ=None, executable=None, port=None):
+    """What a bench entry point started as ``python <script> --gpus N ...`` has to do, decided BEFORE anything touches
+    the GPU (the reference's multi-GPU entry is one process driving N devices, tools/train_rcnn.py:221-223; here it is one
+    process per GPU):
+
+      ("run", None)    this process is a rank: either torch.distributed.run started it (WORLD_SIZE set and equal to
+                       --gpus) or a single GPU was asked for;
+      ("spawn", cmd)   --gpus N > 1 without a torch.distributed.run environment: start `cmd` (the same script under
+                       ``python -m torch.distributed.run --nproc-per-node N``) as a CHILD process and exit with its
+                       code -- never exec: a process that has initialised the GPU must not be replaced.
+
+    A torch.distributed.run environment whose WORLD_SIZE contradicts --gpus raises ValueError (a line claiming N GPUs
+    measured on another number of ranks would be a wrong measurement)."""
+    import sys
+    environ = os.environ if environ is None else environ
+    if gpus < 1:
+        raise ValueError("--gpus must be >= 1, got %d" % gpus)
+    if "WORLD_SIZE" in environ:
+        world = int(environ["WORLD_SIZE"])
+        if world != gpus:
+            raise ValueError("--gpus %d but torch.distributed.run started %d ranks (WORLD_SIZE)" % (gpus, world))
+        return "run", None
+    if gpus == 1:
+        return "run", None
+    if port is None:
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    cmd = [executable or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
+    return "spawn", cmd
+
+
+def launch_or_continue(gpus, script, argv):
+    """bench entry points call this first. Returns None when this process should go on as a rank; otherwise the ranks ran
+    as child processes and the caller exits with the returned code."""
+    import subprocess
+    action, cmd = launch_plan(gpus, script, argv)
+    if action == "run":
+        return None
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def assert_world(gpus):
+    """every rank: the world torch.distributed.run built is the one --gpus names"""
+    _rank, _local, world = env_world()
+    if world != gpus:
+        raise SystemExit("--gpus %d but this process runs in a world of %d ranks" % (gpus, world))
+    return world
+
+
 def scene_ids(total_scenes, rank, world):
     """global scene ids owned by `rank`: round-robin, every scene owned exactly once"""
     if not (0 <= rank < world):
