@@ -62,3 +62,28 @@ class on_device_of:
         if self.prev is not None:
             torch.cuda.set_device(self.prev)
         return False
+
+
+def writes(*names):
+    """decorator of an extension stand-in: the named arguments (tensors, lists of tensors or None) are OUTPUTS the kernels
+    fill through ``data_ptr()``. The reference's pybind extensions write the same way, invisibly to autograd; here every
+    output's version counter is moved after the launch, so that anything remembered about the old contents (autograd's
+    saved-tensor check, pointnet2_utils.scene_index) is known to be stale."""
+    import functools
+    import inspect
+
+    def deco(fn):
+        params = list(inspect.signature(fn).parameters)
+        slots = [(params.index(n), n) for n in names]
+
+        @functools.wraps(fn)
+        def wrapped(*args, **kwargs):
+            result = fn(*args, **kwargs)
+            for pos, name in slots:
+                out = args[pos] if pos < len(args) else kwargs.get(name)
+                if out is None:
+                    continue
+                torch._C._increment_version(tuple(out) if isinstance(out, (list, tuple)) else (out,))
+            return result
+        return wrapped
+    return deco

@@ -9,11 +9,12 @@ count (iou3d.cpp:73-120) -- but mask AND greedy sweep run on the device; only th
 import torch
 
 from . import _lib
-from ._tensor import dev_ptr, host_ptr, need, on_device_of
+from ._tensor import dev_ptr, host_ptr, need, on_device_of, writes
 
 _F = torch.float32
 
 
+@writes("ans")
 def _pairwise(fn_name, boxes_a, boxes_b, ans):
     pa, pb, po = dev_ptr(boxes_a, "boxes_a", _F), dev_ptr(boxes_b, "boxes_b", _F), dev_ptr(ans, "ans", _F)
     na, nb = boxes_a.size(0), boxes_b.size(0)
@@ -33,6 +34,7 @@ def boxes_iou_bev_gpu(boxes_a, boxes_b, ans_iou):
     return _pairwise("epnet_boxes_iou_bev", boxes_a, boxes_b, ans_iou)
 
 
+@writes("ans_iou3d")
 def boxes_iou3d_fused_gpu(boxes_a, boxes_b, ans_iou3d):
     """(N,7) x (M,7) -> (N,M) 3-D IoU in one launch (not in the reference extension; see epnet_ops.h)"""
     pa, pb, po = dev_ptr(boxes_a, "boxes_a", _F), dev_ptr(boxes_b, "boxes_b", _F), dev_ptr(ans_iou3d, "ans", _F)
@@ -43,6 +45,7 @@ def boxes_iou3d_fused_gpu(boxes_a, boxes_b, ans_iou3d):
     return 1
 
 
+@writes("ans_iou3d")
 def boxes_iou3d_pairs_gpu(boxes_a, boxes_b, ans_iou3d):
     """(K,7), (K,7) -> (K,) 3-D IoU of corresponding pairs in one launch"""
     pa, pb, po = dev_ptr(boxes_a, "boxes_a", _F), dev_ptr(boxes_b, "boxes_b", _F), dev_ptr(ans_iou3d, "ans", _F)
@@ -53,6 +56,7 @@ def boxes_iou3d_pairs_gpu(boxes_a, boxes_b, ans_iou3d):
     return 1
 
 
+@writes("roi_boxes3d", "iou_of_rois")
 def aug_roi_by_noise_gpu(roi_boxes3d, gt_boxes3d, iou3d_src, keep_draw, noise, pos_thresh, iou_of_rois, tries=None):
     """the ROI augmentation loop of lib/rpn/proposal_target_layer.py:220-247 for all K ROIs in one launch; roi_boxes3d
     (K,7) is updated in place; keep_draw (K,T) uint8, noise (K,T,7), tries (K) int32 per-ROI try limits or None (not in
@@ -75,6 +79,7 @@ def aug_roi_by_noise_gpu(roi_boxes3d, gt_boxes3d, iou3d_src, keep_draw, noise, p
     return 1
 
 
+@writes("ret_bbox3d", "ret_scores", "ret_count")
 def rpn_proposals_gpu(proposals, scores, order, distance_based, pre_nms_top_n, post_nms_top_n, nms_thresh, rotated,
                       ret_bbox3d, ret_scores, ret_count=None):
     """lib/rpn/proposal_layer.py:34-55 for the whole batch, no host sync: proposals (B,N,7), scores (B,N), order (B,N)

@@ -9,11 +9,12 @@ ABI in libepnet_hip.so. Failures raise RuntimeError; the reference prints and ex
 import torch
 
 from . import _lib
-from ._tensor import dev_ptr, need, on_device_of
+from ._tensor import dev_ptr, need, on_device_of, writes
 
 _F, _I = torch.float32, torch.int32
 
 
+@writes("idx")
 def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
     """ball_query_wrapper_fast, pointnet2_lib/pointnet2/src/ball_query.cpp:14-25"""
     pn, px, pi = dev_ptr(new_xyz, "new_xyz", _F), dev_ptr(xyz, "xyz", _F), dev_ptr(idx, "idx", _I)
@@ -29,6 +30,7 @@ def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
     return 1
 
 
+@writes("out")
 def group_points_wrapper(b, c, n, npoints, nsample, points, idx, out):
     """group_points_wrapper_fast, group_points.cpp:25-36"""
     pp, pi, po = dev_ptr(points, "points", _F), dev_ptr(idx, "idx", _I), dev_ptr(out, "out", _F)
@@ -38,6 +40,7 @@ def group_points_wrapper(b, c, n, npoints, nsample, points, idx, out):
     return 1
 
 
+@writes("grad_points")
 def group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_points):
     """group_points_grad_wrapper_fast, group_points.cpp:11-22"""
     pg, pi, pp = dev_ptr(grad_out, "grad_out", _F), dev_ptr(idx, "idx", _I), dev_ptr(grad_points, "grad_points", _F)
@@ -55,6 +58,7 @@ def group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_poi
     return 1
 
 
+@writes("out")
 def gather_points_wrapper(b, c, n, npoints, points, idx, out):
     """gather_points_wrapper_fast, sampling.cpp:11-20"""
     pp, pi, po = dev_ptr(points, "points", _F), dev_ptr(idx, "idx", _I), dev_ptr(out, "out", _F)
@@ -64,6 +68,7 @@ def gather_points_wrapper(b, c, n, npoints, points, idx, out):
     return 1
 
 
+@writes("grad_points")
 def gather_points_grad_wrapper(b, c, n, npoints, grad_out, idx, grad_points):
     """gather_points_grad_wrapper_fast, sampling.cpp:23-33"""
     pg, pi, pp = dev_ptr(grad_out, "grad_out", _F), dev_ptr(idx, "idx", _I), dev_ptr(grad_points, "grad_points", _F)
@@ -73,6 +78,7 @@ def gather_points_grad_wrapper(b, c, n, npoints, grad_out, idx, grad_points):
     return 1
 
 
+@writes("temp", "idx")
 def furthest_point_sampling_wrapper(b, n, m, points, temp, idx):
     """furthest_point_sampling_wrapper, sampling.cpp:36-46"""
     pp, pt, pi = dev_ptr(points, "points", _F), dev_ptr(temp, "temp", _F), dev_ptr(idx, "idx", _I)
@@ -90,6 +96,7 @@ def furthest_point_sampling_wrapper(b, n, m, points, temp, idx):
     return 1
 
 
+@writes("dist2", "idx")
 def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
     """three_nn_wrapper_fast, interpolate.cpp:14-23"""
     pu, pk = dev_ptr(unknown, "unknown", _F), dev_ptr(known, "known", _F)
@@ -105,6 +112,7 @@ def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
             _lib.check(l.epnet_three_nn(b, n, m, pu, pk, pd, pi, s), "three_nn")
 
 
+@writes("out")
 def three_interpolate_wrapper(b, c, m, n, points, idx, weight, out):
     """three_interpolate_wrapper_fast, interpolate.cpp:26-38"""
     pp, pi = dev_ptr(points, "points", _F), dev_ptr(idx, "idx", _I)
@@ -114,6 +122,7 @@ def three_interpolate_wrapper(b, c, m, n, points, idx, weight, out):
         _lib.check(_lib.lib().epnet_three_interpolate(b, c, m, n, pp, pi, pw, po, s), "three_interpolate")
 
 
+@writes("grad_points")
 def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_points):
     """three_interpolate_grad_wrapper_fast, interpolate.cpp:41-54"""
     pg, pi = dev_ptr(grad_out, "grad_out", _F), dev_ptr(idx, "idx", _I)
@@ -155,6 +164,7 @@ def scene_index(xyz):
     return index
 
 
+@writes("index")
 def scene_index_build_wrapper(b, n, xyz, index):
     """rebuild into a caller-owned buffer of epnet_scene_index_bytes(b, n) bytes (graph-capturable)"""
     px = dev_ptr(xyz, "xyz", _F)
@@ -172,6 +182,7 @@ def _index_args(index, like):
     return index.data_ptr(), index.numel()
 
 
+@writes("temp", "idx")
 def furthest_point_sampling_indexed_wrapper(b, n, m, points, index, temp, idx):
     """furthest_point_sampling_wrapper over a scene index of `points` (same results)"""
     pp, pt, pi = dev_ptr(points, "points", _F), dev_ptr(temp, "temp", _F), dev_ptr(idx, "idx", _I)
@@ -182,6 +193,7 @@ def furthest_point_sampling_indexed_wrapper(b, n, m, points, index, temp, idx):
     return 1
 
 
+@writes("idx", "new_xyz")
 def sample_centres_wrapper(b, n, m, points, index, idx, new_xyz):
     """furthest_point_sampling from a fresh state + gather of the selected rows: idx (B,M) and new_xyz (B,M,3)"""
     pp, pi, pn = dev_ptr(points, "points", _F), dev_ptr(idx, "idx", _I), dev_ptr(new_xyz, "new_xyz", _F)
@@ -194,6 +206,7 @@ def sample_centres_wrapper(b, n, m, points, index, idx, new_xyz):
     return 1
 
 
+@writes("idxs")
 def ball_query_multi_wrapper(b, n, m, radii, nsamples, new_xyz, xyz, index, idxs):
     """the ball queries of all scales of an MSG level in one launch (same results as one ball_query per scale)"""
     import ctypes
@@ -216,6 +229,7 @@ def ball_query_multi_wrapper(b, n, m, radii, nsamples, new_xyz, xyz, index, idxs
     return 1
 
 
+@writes("dist2", "idx")
 def three_nn_indexed_wrapper(b, n, m, unknown, known, unknown_index, known_index, dist2, idx):
     """three_nn_wrapper over scene indices of `known` and (optionally) of `unknown` (same results)"""
     pu, pk = dev_ptr(unknown, "unknown", _F), dev_ptr(known, "known", _F)
@@ -228,6 +242,7 @@ def three_nn_indexed_wrapper(b, n, m, unknown, known, unknown_index, known_index
     return 1
 
 
+@writes("idx")
 def ball_query_indexed_wrapper(b, n, m, radius, nsample, new_xyz, xyz, index, idx):
     """ball_query_wrapper over a scene index of `xyz` (same results)"""
     pn, pxyz, pi = dev_ptr(new_xyz, "new_xyz", _F), dev_ptr(xyz, "xyz", _F), dev_ptr(idx, "idx", _I)
@@ -237,6 +252,7 @@ def ball_query_indexed_wrapper(b, n, m, radius, nsample, new_xyz, xyz, index, id
         _lib.check(_lib.lib().epnet_ball_query_indexed(b, n, m, radius, nsample, pn, pxyz, px, nb, pi, s), "ball_query")
     return 1
 
+@writes("out")
 def group_concat_wrapper(b, c, n, npoints, nsample, xyz, new_xyz, features, idx, out, use_xyz):
     """out (B, 3+C | C, M, ns) = [grouped xyz - centre ; grouped features]; features may be None when c == 0"""
     px = dev_ptr(xyz, "xyz", _F) if use_xyz else None
@@ -254,6 +270,7 @@ def group_concat_wrapper(b, c, n, npoints, nsample, xyz, new_xyz, features, idx,
     return 1
 
 
+@writes("outs")
 def group_concat_multi_wrapper(b, c, n, npoints, nsamples, xyz, new_xyz, features, idxs, outs, use_xyz):
     """group_concat_wrapper for all scales of an MSG level in one call (the feature rows are staged once for two scales)"""
     import ctypes
@@ -280,6 +297,7 @@ def group_concat_multi_wrapper(b, c, n, npoints, nsamples, xyz, new_xyz, feature
     return 1
 
 
+@writes("grad_features")
 def group_concat_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_features, use_xyz):
     pg, pi, pp = dev_ptr(grad_out, "grad_out", _F), dev_ptr(idx, "idx", _I), dev_ptr(grad_features, "grad_features", _F)
     need(grad_out, b * ((3 if use_xyz else 0) + c) * npoints * nsample, "grad_out"); need(grad_features, b * c * n, "grad_features")
@@ -296,6 +314,7 @@ def group_concat_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_fea
     return 1
 
 
+@writes("out", "arg")
 def pool_max_wrapper(rows, nsample, x, out, arg):
     """the SA level's neighbourhood max-pool (F.max_pool2d(kernel_size=[1, nsample]), pointnet2_modules.py:61-68): x
     (rows, nsample) -> out (rows), arg (rows) int32 or None (not in the reference extension; see epnet_ops.h)"""
@@ -309,6 +328,7 @@ def pool_max_wrapper(rows, nsample, x, out, arg):
     return 1
 
 
+@writes("grad_x")
 def pool_max_grad_wrapper(rows, nsample, grad_out, arg, grad_x):
     pg, pa, px = dev_ptr(grad_out, "grad_out", _F), dev_ptr(arg, "arg", _I), dev_ptr(grad_x, "grad_x", _F)
     need(grad_out, rows, "grad_out"); need(arg, rows, "arg"); need(grad_x, rows * nsample, "grad_x")
@@ -317,6 +337,7 @@ def pool_max_grad_wrapper(rows, nsample, grad_out, arg, grad_x):
     return 1
 
 
+@writes("out")
 def group_linear_wrapper(b, c, n, npoints, nsample, xyz, new_xyz, z, idx, w_xyz, bias, out):
     """the first shared-MLP layer of an SA level folded into its grouping: out (b,c,npoints,nsample) =
     z[:, :, idx] + w_xyz . (xyz[idx] - centre) (+ bias); z (b,c,n) = W_f . features (not in the reference extension; see
@@ -333,6 +354,7 @@ def group_linear_wrapper(b, c, n, npoints, nsample, xyz, new_xyz, z, idx, w_xyz,
     return 1
 
 
+@writes("grad_w")
 def group_linear_grad_w_wrapper(b, c, n, npoints, nsample, grad_out, xyz, new_xyz, idx, grad_w):
     """grad_w (c,3), zero-filled by the caller, += sum of grad_out[b,co,m,s] * (xyz[idx] - centre)[k]"""
     pg, px, pn = dev_ptr(grad_out, "grad_out", _F), dev_ptr(xyz, "xyz", _F), dev_ptr(new_xyz, "new_xyz", _F)
@@ -344,6 +366,7 @@ def group_linear_grad_w_wrapper(b, c, n, npoints, nsample, grad_out, xyz, new_xy
     return 1
 
 
+@writes("out", "xy_out")
 def feature_gather_wrapper(b, c, h, w, n_src, n, align_corners, feature_map, xy, idx, out, xy_out):
     """LI-Fusion's point-to-pixel bilinear sampler (lib/net/pointnet2_msg.py:107-120) with the xy gather over the FPS
     indices folded in (not in the reference extension; see epnet_ops.h)"""
@@ -361,6 +384,7 @@ def feature_gather_wrapper(b, c, h, w, n_src, n, align_corners, feature_map, xy,
     return 1
 
 
+@writes("grad_feature_map")
 def feature_gather_grad_wrapper(b, c, h, w, n, align_corners, grad_out, xy, grad_feature_map):
     pg, px, pf = dev_ptr(grad_out, "grad_out", _F), dev_ptr(xy, "xy", _F), dev_ptr(grad_feature_map, "grad_feature_map", _F)
     need(grad_out, b * c * n, "grad_out"); need(xy, b * n * 2, "xy"); need(grad_feature_map, b * c * h * w, "grad_feature_map")

@@ -60,13 +60,14 @@ class _PointnetSAModuleBase(nn.Module):
         """xyz (B,N,3), features (B,C,N) -> (new_xyz (B,npoint,3), new_features (B,sum mlp[-1],npoint),
         idx (B,npoint) int32 FPS indices or None). The 3-tuple (reference :72) is what
         lib/net/pointnet2_msg.py:214-218 unpacks; LI-Fusion consumes idx."""
-        idx = None
-        if presampled is not None:   # (idx, new_xyz, event) of pointnet2_utils.sample_pyramid: the level's sampling, done up front
-            idx, new_xyz, ready = presampled
+        idx = index = None
+        if presampled is not None:   # (idx, new_xyz, event, index) of pointnet2_utils.sample_pyramid: the level's sampling, done up front
+            idx, new_xyz, ready, index = presampled
             assert new_xyz.shape[1] == self.npoint
             torch.cuda.current_stream(xyz.device).wait_event(ready)
         # one spatial sort of the level's points serves the sampling and every ball query of the level
-        index = pointnet2_utils.scene_index(xyz) if self.npoint is not None and xyz.is_cuda else None
+        if index is None and self.npoint is not None and xyz.is_cuda:
+            index = pointnet2_utils.scene_index(xyz)
         if new_xyz is None and self.npoint is not None:
             if xyz.is_cuda and xyz.is_contiguous() and not (torch.is_grad_enabled() and xyz.requires_grad):
                 idx, new_xyz = pointnet2_utils.sample_and_gather(xyz, self.npoint, index)  # one kernel, same values
@@ -74,6 +75,8 @@ class _PointnetSAModuleBase(nn.Module):
                 idx = pointnet2_utils.furthest_point_sample(xyz, self.npoint, index)
                 channels_first = xyz.transpose(1, 2).contiguous()
                 new_xyz = pointnet2_utils.gather_operation(channels_first, idx).transpose(1, 2).contiguous()
+                if not new_xyz.requires_grad:
+                    new_xyz = pointnet2_utils._own(new_xyz)
 
         # the ball queries of all scales share one walk over the index (nested balls around the same centres)
         idxs = None
@@ -158,7 +161,8 @@ class PointnetFPModule(nn.Module):
         if known is None:
             spread = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
         else:
-            # the SA modules of the two levels have indexed both point sets already (pointnet2_utils.scene_index)
+            # the centres an SA level produced carry the index the next level built of them (pointnet2_utils.scene_index);
+            # a caller's own tensor (the input cloud) is indexed afresh -- nothing remembered could be trusted for it
             known_index = pointnet2_utils.scene_index(known)
             unknown_index = pointnet2_utils.scene_index(unknown) if known_index is not None else None
             dist, idx = pointnet2_utils.three_nn(unknown, known, unknown_index, known_index)

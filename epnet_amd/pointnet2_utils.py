@@ -8,7 +8,7 @@ plumbing: outputs are allocated on the INPUT's device (the reference uses
 ``torch.cuda.FloatTensor(...)``, i.e. whatever device is current), and errors raise instead of
 killing the process.
 """
-import weakref
+import threading
 from typing import Optional, Tuple
 
 import torch
@@ -49,42 +49,54 @@ class FurthestPointSampling(Function):
 furthest_point_sample = FurthestPointSampling.apply
 
 
-_INDEX_CACHE = {}  # id(tensor) -> (weakref, tensor._version, index, capture epoch): the SA level's index is found again by its FP module
 _CAPTURE = {"epoch": 0, "was_capturing": False}
+_CAPTURE_LOCK = threading.Lock()   # nn.DataParallel runs replica forward passes in threads
 
 
 def _capture_epoch() -> int:
-    """0 outside HIP-graph capture, a fresh positive number for every capture. A graph replay rewrites tensors without
-    touching their version counters, so an index remembered eagerly must not be baked into a graph (the graph would keep
-    using the index of the capture-time coordinates), and one built inside a capture says nothing about the tensor's
-    content afterwards: remembered indices are only valid within the capture (or the eager stretch) that built them."""
+    """0 outside HIP-graph capture, a fresh positive number for every capture. An index built inside a capture lives in
+    the graph's memory pool and is only meaningful to launches recorded into the same graph; one built eagerly must not be
+    baked into a graph."""
     capturing = torch.cuda.is_current_stream_capturing() if torch.cuda.is_available() else False
-    if capturing and not _CAPTURE["was_capturing"]:
-        _CAPTURE["epoch"] += 1
-    _CAPTURE["was_capturing"] = capturing
-    return _CAPTURE["epoch"] if capturing else 0
+    with _CAPTURE_LOCK:
+        if capturing and not _CAPTURE["was_capturing"]:
+            _CAPTURE["epoch"] += 1
+        _CAPTURE["was_capturing"] = capturing
+        return _CAPTURE["epoch"] if capturing else 0
+
+
+def _own(t: torch.Tensor) -> torch.Tensor:
+    """marks a tensor this package has just allocated and filled itself (the centres of an SA level). Only such tensors
+    may carry a remembered scene index: nobody else holds a reference to them yet, every later write through torch or
+    through this package's stand-ins moves their version counter, and inside a HIP graph they are rewritten together with
+    their index by the same replay. A CALLER's tensor never carries one -- a graph replay, a ``.data`` write or a foreign
+    extension writing through ``data_ptr()`` changes its content without any trace, and a remembered index would then
+    silently answer for the old coordinates."""
+    t._epnet_owned = True
+    return t
 
 
 def scene_index(xyz: torch.Tensor, cached_only: bool = False) -> Optional[torch.Tensor]:
     """one spatial sort of the (B,N,3) points of an SA level for furthest_point_sample / ball_query /
     QueryAndGroup / three_nn (their optional trailing arguments); None where the library indexes nothing.
-    Beyond the reference: its kernels scan all N points each. The index of a tensor object is remembered
-    while that object lives and is not written to, so the FP module of a level finds the index its SA
-    module built (``cached_only``: look up, do not build)."""
+    Beyond the reference: its kernels scan all N points each.
+
+    The index travels as an attribute of the tensor object it was built from, and only on tensors this package
+    allocated itself (``_own``): the centres an SA level hands to the next level and to its FP module. It is served again
+    only while the tensor's version counter and the capture epoch are the ones it was built under. For any other tensor
+    every call builds a fresh index (``cached_only``: look up, do not build)."""
     if not xyz.is_cuda or not xyz.is_contiguous():
         return None
-    key = id(xyz)
     epoch = _capture_epoch()
-    hit = _INDEX_CACHE.get(key)
-    if hit is not None and hit[0]() is xyz and hit[1] == xyz._version and hit[3] == epoch:
-        return hit[2]
+    version = None if xyz.is_inference() else xyz._version     # inference tensors track no version: nothing is remembered
+    hit = getattr(xyz, "_epnet_index", None)
+    if hit is not None and version is not None and hit[1] == version and hit[2] == epoch:
+        return hit[0]
     if cached_only:
         return None
     index = _ext.scene_index(xyz.detach())
-    if index is not None:
-        if len(_INDEX_CACHE) > 64:
-            _INDEX_CACHE.clear()
-        _INDEX_CACHE[key] = (weakref.ref(xyz, lambda _r, _k=key: _INDEX_CACHE.pop(_k, None)), xyz._version, index, epoch)
+    if index is not None and version is not None and getattr(xyz, "_epnet_owned", False):
+        xyz._epnet_index = (index, version, epoch)
     return index
 
 
@@ -98,7 +110,7 @@ def sample_and_gather(xyz: torch.Tensor, npoint: int, index: Optional[torch.Tens
     idx = _new(xyz, (batch, npoint), torch.int32)
     new_xyz = _new(xyz, (batch, npoint, 3))
     _ext.sample_centres_wrapper(batch, n, npoint, xyz.detach(), index, idx, new_xyz)
-    return idx, new_xyz
+    return idx, _own(new_xyz)
 
 
 _PYRAMID_STREAMS = {}
@@ -130,7 +142,7 @@ def sample_pyramid(xyz: torch.Tensor, npoints):
             for t in (idx, new_xyz, index):       # allocated on the side stream, consumed on the caller's
                 if t is not None:
                     t.record_stream(main)
-            levels.append((idx, new_xyz, event))
+            levels.append((idx, new_xyz, event, index))
             cur = new_xyz
     return levels
 

@@ -2,11 +2,12 @@
 import torch
 
 from . import _lib
-from ._tensor import dev_ptr, host_ptr, need, on_device_of
+from ._tensor import dev_ptr, host_ptr, need, on_device_of, writes
 
 _F = torch.float32
 
 
+@writes("pooled_features", "pooled_empty_flag")
 def forward(xyz, boxes3d, pts_feature, pooled_features, pooled_empty_flag):
     """roipool3d_gpu, roipool3d.cpp:48-79 (S is read from pooled_features.size(2), :64)"""
     px, pb, pf = dev_ptr(xyz, "xyz", _F), dev_ptr(boxes3d, "boxes3d", _F), dev_ptr(pts_feature, "pts_feature", _F)
@@ -24,6 +25,7 @@ def forward(xyz, boxes3d, pts_feature, pooled_features, pooled_empty_flag):
 forward_slow = forward
 
 
+@writes("pts_flag")
 def pts_in_boxes3d_cpu(pts_flag, pts, boxes3d):
     """roipool3d.cpp:97-125 -- a HOST op in the reference as well"""
     pf, pp, pb = host_ptr(pts_flag, "pts_flag", torch.int64), host_ptr(pts, "pts", _F), host_ptr(boxes3d, "boxes3d", _F)
@@ -33,6 +35,7 @@ def pts_in_boxes3d_cpu(pts_flag, pts, boxes3d):
     return 1
 
 
+@writes("pooled_pts", "pooled_features", "pooled_empty_flag")
 def roipool3d_cpu(pts, boxes3d, pts_feature, pooled_pts, pooled_features, pooled_empty_flag):
     """roipool3d.cpp:127-195 -- a HOST op in the reference as well"""
     pp, pb, pf = host_ptr(pts, "pts", _F), host_ptr(boxes3d, "boxes3d", _F), host_ptr(pts_feature, "pts_feature", _F)
