@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--cpu-scenes", type=int, default=int(os.environ.get("EPNET_BENCH_CPU_SCENES", "16")),
                     help="scenes in the cpu_baseline sample (0 = skip)")
     ap.add_argument("--sweep", default="", help="comma list of extra batch sizes to time (reported under 'sweep')")
+    ap.add_argument("--verify-scenes", type=int, default=1,
+                    help="scenes of the timed buffers rank 0 checks against the CPU oracle after the timed loop (0 = skip; "
+                         "the line then carries verified: null)")
     ap.add_argument("--launch-check", action="store_true",
                     help="rehearse the N-rank launch only: the ranks rendezvous (backend EPNET_BENCH_BACKEND, default nccl), "
                          "count themselves with an all-reduce and rank 0 prints n_gpus / ranks_seen; no kernels of the path")
@@ -126,6 +129,62 @@ def cpu_baseline_multicore(kind, n_points, procs):
         wall = time.perf_counter() - t0
     return {"value": len(seeds) * n_points / wall, "unit": "points/s", "cores": procs, "kind": "port",
             "sample": "%d %s scenes over %d worker processes, %.1f s wall" % (len(seeds), kind, procs, wall)}
+
+
+def verify_scene(stack, xyz, scene):
+    """One scene of the buffers the timed steps left behind, checked against the CPU oracle DIRECTLY (not against another
+    HIP path): every level's FPS indices and centres, both ball-query index tensors, both grouped tensors
+    [xyz - centre ; features] (and, with the FP ops in the step, three_nn / three_interpolate). Integer outputs and copies
+    must be identical; the interpolation is held to 1e-5. Returns the list of mismatching outputs (empty = verified).
+    The oracle is the checker here, outside every timed region (oracle/oracle.py header)."""
+    import numpy as np
+    from oracle import oracle
+    oracle.build()
+    bad = []
+
+    def same(name, got, want, tol=None):
+        got = got.detach().cpu().numpy()
+        ok = np.array_equal(got, want) if tol is None else np.allclose(got, want, rtol=tol, atol=tol)
+        if not ok:
+            bad.append(name)
+
+    cur = xyz[scene:scene + 1].detach().cpu().numpy()
+    clouds = [cur]
+    for lvl, L in enumerate(stack.levels):
+        tag = "level%d." % (lvl + 1)
+        cur_t = np.ascontiguousarray(cur.transpose(0, 2, 1))
+        fps = oracle.furthest_point_sampling(cur, L["m"])
+        new_xyz = np.ascontiguousarray(oracle.gather_points(cur_t, fps).transpose(0, 2, 1))
+        same(tag + "fps_idx", L["fps_idx"][scene:scene + 1], fps)
+        for k, P in enumerate(L["sets"]):
+            same(tag + "new_xyz[set %d]" % k, P["new_xyz"][scene:scene + 1], new_xyz)
+        feats = None if L["features"] is None else L["features"][scene:scene + 1].cpu().numpy()
+        for S in L["scales"]:
+            stag = tag + "r%g." % S["radius"]
+            bq = oracle.ball_query(S["radius"], S["ns"], cur, new_xyz)
+            same(stag + "ball_idx", S["idx"][scene:scene + 1], bq)
+            want_xyz = oracle.group_points(cur_t, bq) - new_xyz.transpose(0, 2, 1)[:, :, :, None]   # pointnet2_utils.py:250-251
+            want_feat = None if feats is None else oracle.group_points(feats, bq)
+            if stack.fused:
+                want = want_xyz if want_feat is None else np.concatenate([want_xyz, want_feat], axis=1)  # :254-257
+                same(stag + "grouped", S["grouped"][scene:scene + 1], want)
+            else:
+                same(stag + "grouped_xyz", S["grouped_xyz"][scene:scene + 1], oracle.group_points(cur_t, bq))
+                if want_feat is not None:
+                    same(stag + "grouped_feat", S["grouped_feat"][scene:scene + 1], want_feat)
+        cur = new_xyz
+        clouds.append(cur)
+    for k, F in enumerate(stack.fp_bufs if stack.with_fp else []):
+        tag = "fp%d." % (len(stack.levels) - k)
+        known, unknown = clouds[len(stack.levels) - k], clouds[len(stack.levels) - k - 1]
+        d2, nn_idx = oracle.three_nn(unknown, known)
+        same(tag + "three_nn.idx", F["idx"][scene:scene + 1], nn_idx)
+        same(tag + "three_nn.dist2", F["dist2"][scene:scene + 1], d2)
+        inv = (np.float32(1.0) / (np.sqrt(d2) + np.float32(1e-8))).astype(np.float32)     # pointnet2_modules.py:157-159
+        weight = (inv / inv.sum(axis=2, keepdims=True)).astype(np.float32)
+        want = oracle.three_interpolate(F["known_feats"][scene:scene + 1].cpu().numpy(), nn_idx, weight)
+        same(tag + "three_interpolate", F["out"][scene:scene + 1], want, tol=1e-5)
+    return bad
 
 
 class OpTimer:
@@ -313,6 +372,25 @@ def main():
     elapsed = scene_shard.max_over_ranks(elapsed, device=reduce_dev)
     points_per_step = world * args.batch * args.points
     value = points_per_step * args.steps / elapsed
+    ranks_seen = int(scene_shard.sum_over_ranks(1.0, device=reduce_dev))   # the ranks the collective library saw
+
+    # ---- what the timed steps left in the buffers, against the oracle (rank 0, outside every timed region)
+    verification = None
+    if rank == 0 and args.verify_scenes > 0:
+        torch.cuda.synchronize()
+        picks = sorted({0, args.batch - 1} if args.verify_scenes > 1 else {0})
+        picks += [s_ for s_ in range(1, args.batch - 1)][:max(0, args.verify_scenes - len(picks))]
+        mism = {}
+        for s_ in picks:
+            bad = verify_scene(stack, stack.static_xyz if stack.static_xyz is not None else xyz, s_)
+            if bad:
+                mism[str(s_)] = bad
+        verification = {"verified": not mism, "scenes": picks, "mismatches": mism,
+                        "checked": "fps_idx, centres, ball-query idx and grouped tensors of all %d levels%s of the timed buffers "
+                                   "(%s) vs oracle/epnet_oracle.c: identical"
+                                   % (len(stack.levels), " + three_nn / three_interpolate (1e-5)" if args.with_fp else "",
+                                      "pipelined HIP-graph replays" if (args.pipelined and not args.no_graph) else
+                                      ("HIP-graph replays" if not args.no_graph else "eager steps"))}
 
     # ---- per-kernel durations: the same K steps replayed eagerly with HIP events around every launch
     stack.overlap = False  # single stream, unpipelined here, so that an event pair brackets exactly its own kernel
@@ -390,7 +468,11 @@ def main():
             "device_copy_GBps": round(copy_gbs, 1), "stack_frac_of_device_copy": round(stack_gbs / copy_gbs, 6),
             "roofline": roofline, "roofline_hbm_bound": roofline_hbm, "kernels": kernels, "cpu_baseline": cpu,
             "cpu_baseline_multicore": cpu_multi,
+            "verified": None if verification is None else verification["verified"], "verification": verification,
+            "ranks_seen": ranks_seen,
         }
+        if world > 1:
+            line["cpu_baseline_note"] = "the CPU baseline is timed in the N = 1 run only (rank 0 there has the host to itself)"
         if sweep:
             line["sweep"] = sweep
         print(json.dumps(line), flush=True)

@@ -114,6 +114,28 @@ def test_fps_golden_fixtures():
     np.testing.assert_array_equal(host(p2u.furthest_point_sample(dev(ft["odd_xyz"]), 300)), ft["odd_idx"])
 
 
+def test_config1_fixture_on_the_gpu():
+    """BASELINE config 1 end to end on the GPU against the committed fixture (captured from the reference's own Python
+    surface): FPS, gather, both ball queries (r = 0.1: nearly empty balls, r = 2.0: saturated) and QueryAndGroup"""
+    from epnet_amd import pointnet2_utils as p2u
+    fx = golden("pointnet2_cfg1.npz")
+    xyz = dev(fx["xyz"])
+    for index in (None, p2u.scene_index(xyz)):
+        fps = p2u.furthest_point_sample(xyz, 1024, index)
+        np.testing.assert_array_equal(host(fps), fx["fps_idx"])
+        new_xyz = p2u.gather_operation(xyz.transpose(1, 2).contiguous(), fps).transpose(1, 2).contiguous()
+        np.testing.assert_array_equal(host(new_xyz), fx["new_xyz"])
+        np.testing.assert_array_equal(host(p2u.ball_query(0.1, 32, xyz, new_xyz, index)), fx["ball_idx_r01"])
+        np.testing.assert_array_equal(host(p2u.ball_query(2.0, 32, xyz, new_xyz, index)), fx["ball_idx_r20"])
+        np.testing.assert_array_equal(host(p2u.QueryAndGroup(2.0, 32)(xyz, new_xyz, None, index)), fx["query_and_group_r20"])
+    both = p2u.ball_query_multi([0.1, 2.0], [32, 32], xyz, dev(fx["new_xyz"]))
+    np.testing.assert_array_equal(host(both[0]), fx["ball_idx_r01"])
+    np.testing.assert_array_equal(host(both[1]), fx["ball_idx_r20"])
+    idx2, centres = p2u.sample_and_gather(xyz, 1024, None)
+    np.testing.assert_array_equal(host(idx2), fx["fps_idx"])
+    np.testing.assert_array_equal(host(centres), fx["new_xyz"])
+
+
 def test_fps_full_size_properties():
     """B = 16 scenes of 16384 points -> 4096: index 0 first, all indices distinct (the clouds have no
     duplicate rows), and the greedy max-min property holds for the sequence (checked in float64 on a
@@ -893,3 +915,34 @@ def test_ops_follow_the_current_stream_and_graph_replay(oracle):
         for a, b in zip(eager, outputs(piped, parity=1 - (k & 1))):
             np.testing.assert_array_equal(a, b)
     np.testing.assert_array_equal(eager[0], oracle.furthest_point_sampling(xyz_h.numpy(), 1024))
+
+
+@pytest.mark.parametrize("with_fp,kind", [(False, "kitti"), (True, "kitti"), (False, "dup")])
+def test_the_benchs_own_configuration_against_the_oracle(oracle, with_fp, kind):
+    """exactly what bench.py times -- SAStack at 16384 points, software-pipelined, captured into two HIP graphs, the
+    kernels the 256-scene run uses (fps_indexed_kernel<8,32>, the multi-scale ball query, group_concat_multi) -- with
+    every fps_idx / centre / ball-query idx / grouped tensor of every level compared with the ORACLE directly
+    (bench.verify_scene, the check the bench itself prints as `verified`)"""
+    import bench
+    from epnet_amd import sa_stack, synth
+    b = 2
+    xyz = synth.scenes(kind, b, 16384, seed=77).to(DEV)
+    stack = sa_stack.SAStack(b, n=16384, device=DEV, with_fp=with_fp, seed=5, pipelined=True, fused_sampling=True)
+    stack.capture(xyz)
+    for L in stack.levels:        # nothing of the capture-time warm-up may survive into the comparison
+        L["fps_idx"].fill_(-1)
+        for P in L["sets"]:
+            P["new_xyz"].zero_()    # (read as centres by the first replay's grouping stage: keep them finite)
+        for S in L["scales"]:
+            S["idx"].zero_()
+            S["grouped"].fill_(float("nan"))
+    for F in stack.fp_bufs:
+        F["idx"].fill_(-1); F["dist2"].fill_(float("nan")); F["out"].fill_(float("nan"))
+    for _ in range(3):            # both graphs of the rotation; the third replay regroups what the second one sampled
+        stack.replay()
+    torch.cuda.synchronize()
+    for scene in range(b):
+        assert bench.verify_scene(stack, stack.static_xyz, scene) == []
+    # the checker does notice a wrong buffer
+    stack.levels[1]["scales"][0]["idx"][0, 5, 3] += 1
+    assert bench.verify_scene(stack, stack.static_xyz, 0) == ["level2.r0.5.ball_idx"]
