@@ -896,8 +896,9 @@ extern "C" int epnet_furthest_point_sampling(int b, int n, int m, const float *x
     dim3 grid(b);
     const int J = div_up(n, bs_ref);
     // 1024 < n <= 16384: exact spatially-pruned kernel (EPNET_FPS_PRUNE=0 forces the brute-force path)
-    static const bool prune_enabled = !(getenv("EPNET_FPS_PRUNE") && atoi(getenv("EPNET_FPS_PRUNE")) == 0);
-    static const int prune_min = getenv("EPNET_FPS_PRUNE_MIN") ? atoi(getenv("EPNET_FPS_PRUNE_MIN")) : 1024;
+    // (the tuning variables are read on every call, so that the one-process GPU test run reaches every variant)
+    const bool prune_enabled = !(getenv("EPNET_FPS_PRUNE") && atoi(getenv("EPNET_FPS_PRUNE")) == 0);
+    const int prune_min = getenv("EPNET_FPS_PRUNE_MIN") ? atoi(getenv("EPNET_FPS_PRUNE_MIN")) : 1024;
     if (prune_enabled && n > 1024 && n > prune_min && n <= 16384 && m > 1) {
         // 64-point slots: 4 waves x {8,16,32} slots, 8 waves above 8192 points (EPNET_FPS_PWAVES overrides)
         int waves = n > 8192 ? 8 : 4;
@@ -1002,11 +1003,11 @@ static int fps_over_index(int b, int n, int m, const float *xyz, const void *ind
             hipLaunchKernelGGL(pruned::fps_bigscene_kernel, grid, dim3(pruned::kBigThreads), 0, s, n, np, m, xyz, sorted,
                                (const float *)(sorted + (size_t)b * np), temp, idx);
         } else {
-            static const int wide = getenv("EPNET_FPS_WIDE") ? atoi(getenv("EPNET_FPS_WIDE")) : 0;
+            const int wide = getenv("EPNET_FPS_WIDE") ? atoi(getenv("EPNET_FPS_WIDE")) : 0;
             // the centres can come out of the sampling kernel itself (kCtr: the round's winner is in registers anyway) or from a
             // small gather afterwards. In-kernel costs wave 0 an LDS write per round and 12 KB more LDS: 1.7 % on one scene,
             // 5 % in the software-pipelined stack -- more than the extra launch, so the separate gather is the default
-            static const bool ctr_in_kernel = getenv("EPNET_FPS_CTR") && atoi(getenv("EPNET_FPS_CTR")) != 0;
+            const bool ctr_in_kernel = getenv("EPNET_FPS_CTR") && atoi(getenv("EPNET_FPS_CTR")) != 0;
 #define EPNET_FPS_INDEXED(W_, P_)                                                                                          \
     do {                                                                                                                   \
         if (new_xyz && ctr_in_kernel)                                                                                      \

@@ -403,6 +403,7 @@ static int launch_gather_rows(int b, int c, int n, long long p, const float *poi
     if (ostride == 0) ostride = (size_t)c * (size_t)p;
     if (b == 0 || c == 0 || p == 0) return EPNET_OK;
     if (!(points && idx && out)) return EPNET_EINVAL;
+    if (n <= 0) return EPNET_EINVAL;  // positions to fill from an empty cloud: no index can be valid
     if (p > 0x7fffffffll || b > 65535 || div_up(c, kGChan) > 65535) return EPNET_ELIMIT;
     const bool vec = (p % 4 == 0) && (((uintptr_t)idx | (uintptr_t)out) % 16 == 0);
     constexpr int kLdsBudget = EPNET_GATHER_LDS_BUDGET_KB * 1024;  // two workgroups per CU
@@ -661,6 +662,7 @@ extern "C" int epnet_group_concat(int b, int c, int n, int npoints, int nsample,
     const long long p = (long long)npoints * nsample;
     if (b == 0 || p == 0) return EPNET_OK;
     EPNET_REQUIRE(idx && out && (c == 0 || features) && (!use_xyz || (xyz && new_xyz)));
+    EPNET_REQUIRE(n > 0);  // positions to fill from an empty cloud: no index can be valid
     if (p > 0x7fffffffll || b > 65535) return EPNET_ELIMIT;
     hipStream_t s = (hipStream_t)stream;
     const int ch0 = use_xyz ? 3 : 0;
@@ -689,7 +691,7 @@ extern "C" int epnet_group_concat_multi(int b, int c, int n, int npoints, int ns
     hipStream_t s = (hipStream_t)stream;
     const int ch0 = use_xyz ? 3 : 0;
     constexpr int kLdsBudget = EPNET_GATHER_LDS_BUDGET_KB * 1024;
-    bool fused = nscales == 2 && c >= 8 && b > 0 && npoints > 0 && (size_t)n * 4 <= (size_t)kLdsBudget && features && b <= 65535;
+    bool fused = nscales == 2 && c >= 8 && b > 0 && n > 0 && npoints > 0 && (size_t)n * 4 <= (size_t)kLdsBudget && features && b <= 65535;
     int rows = 0;
     if (fused) {
         rows = kLdsBudget / (n * 4);

@@ -41,6 +41,16 @@ def test_argument_validation_without_gpu(hiplib):
     assert hiplib.epnet_group_points(1, 1, 1, 1, 1, None, None, None, None) == -1
     assert hiplib.epnet_nms_workspace_bytes(6300) == 6300 * 99 * 8 + 6300 * 16
     assert hiplib.epnet_nms_workspace_bytes(0) == 0
+    # positions to fill from an EMPTY cloud (n = 0): an error code, not a division by zero on the host
+    import ctypes as C
+    fake = C.c_void_p(4096)   # never dereferenced: the call must return before anything touches the device
+    assert hiplib.epnet_group_points(1, 16, 0, 512, 8, fake, fake, fake, None) == -1
+    assert hiplib.epnet_gather_points(1, 16, 0, 4096, fake, fake, fake, None) == -1
+    assert hiplib.epnet_group_concat(1, 16, 0, 512, 8, fake, fake, fake, fake, fake, 1, None) == -1
+    two = (C.c_int * 2)(8, 8)
+    ptrs = (C.c_void_p * 2)(4096, 4096)
+    assert hiplib.epnet_group_concat_multi(1, 16, 0, 512, 2, C.cast(two, C.c_void_p), fake, fake, fake, C.cast(ptrs, C.c_void_p),
+                                           C.cast(ptrs, C.c_void_p), 1, None) == -1
     # empty problems are no-ops
     assert hiplib.epnet_ball_query(0, 10, 10, 1.0, 4, None, None, None, None) == 0
     assert hiplib.epnet_three_nn(1, 0, 5, None, None, None, None, None) == 0

@@ -114,6 +114,53 @@ def test_fps_golden_fixtures():
     np.testing.assert_array_equal(host(p2u.furthest_point_sample(dev(ft["odd_xyz"]), 300)), ft["odd_idx"])
 
 
+@pytest.mark.parametrize("env,n,m,kind", [
+    ({"EPNET_FPS_PRUNE": "0"}, 16384, 2048, "kitti"),      # brute force over 16 waves x 16 slots instead of the pruned kernel
+    ({"EPNET_FPS_PRUNE": "0"}, 4096, 1024, "dup"),
+    ({"EPNET_FPS_PRUNE": "0"}, 3000, 700, "kitti"),
+    ({"EPNET_FPS_PRUNE_MIN": "4096"}, 4096, 512, "kitti"),  # pruning only above 4096 points
+    ({"EPNET_FPS_PRUNE_MIN": "4096"}, 8192, 512, "dup"),
+    ({"EPNET_FPS_PWAVES": "2"}, 4096, 1024, "kitti"),       # wave counts of the self-sorting pruned kernel
+    ({"EPNET_FPS_PWAVES": "8"}, 4096, 1024, "dup"),
+    ({"EPNET_FPS_PWAVES": "4"}, 16384, 1024, "kitti"),
+    ({"EPNET_FPS_WAVES": "1"}, 1024, 256, "dup"),           # wave counts of the register-resident brute-force kernel
+    ({"EPNET_FPS_WAVES": "4"}, 1024, 256, "kitti"),
+    ({"EPNET_FPS_WAVES": "2"}, 512, 128, "dup"),
+    ({"EPNET_FPS_WIDE": "1"}, 16384, 2048, "kitti"),        # 16 waves x 16 slots over the scene index
+    ({"EPNET_FPS_WIDE": "1"}, 12000, 1500, "dup"),
+    ({"EPNET_FPS_CTR": "1"}, 16384, 2048, "kitti"),         # centres written by the sampling kernel itself, every layout
+    ({"EPNET_FPS_CTR": "1"}, 8192, 1024, "dup"),
+    ({"EPNET_FPS_CTR": "1"}, 4096, 1024, "kitti"),
+    ({"EPNET_FPS_CTR": "1"}, 2048, 512, "kitti"),
+    ({"EPNET_FPS_CTR": "1", "EPNET_FPS_WIDE": "1"}, 16384, 1024, "dup"),
+])
+def test_fps_tuning_variants_match_oracle(oracle, monkeypatch, env, n, m, kind):
+    """every kernel variant an EPNET_FPS_* variable selects (read per call) gives the oracle's indices, running
+    distances and centres: nothing in the product library is out of the tests' reach"""
+    from epnet_amd import pointnet2_cuda as ext
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    b = 2
+    xyz = rand_cloud(b, n, seed=500 + n + m, kind=kind)
+    o_idx, o_temp = oracle.furthest_point_sampling(xyz, m, return_temp=True)
+    d_xyz = dev(xyz)
+    temp = torch.full((b, n), 1e10, device=DEV)
+    idx = torch.full((b, m), -1, dtype=torch.int32, device=DEV)
+    ext.furthest_point_sampling_wrapper(b, n, m, d_xyz, temp, idx)
+    np.testing.assert_array_equal(host(idx), o_idx)
+    np.testing.assert_array_equal(host(temp), o_temp)
+    index = ext.scene_index(d_xyz)
+    temp.fill_(1e10); idx.fill_(-1)
+    ext.furthest_point_sampling_indexed_wrapper(b, n, m, d_xyz, index, temp, idx)
+    np.testing.assert_array_equal(host(idx), o_idx)
+    np.testing.assert_array_equal(host(temp), o_temp)
+    idx.fill_(-1)
+    centres = torch.full((b, m, 3), float("nan"), device=DEV)
+    ext.sample_centres_wrapper(b, n, m, d_xyz, index, idx, centres)
+    np.testing.assert_array_equal(host(idx), o_idx)
+    np.testing.assert_array_equal(host(centres), np.take_along_axis(xyz, o_idx[:, :, None].astype(np.int64), axis=1))
+
+
 def test_config1_fixture_on_the_gpu():
     """BASELINE config 1 end to end on the GPU against the committed fixture (captured from the reference's own Python
     surface): FPS, gather, both ball queries (r = 0.1: nearly empty balls, r = 2.0: saturated) and QueryAndGroup"""
