@@ -190,21 +190,23 @@ def verify_scene(stack, xyz, scene):
 class OpTimer:
     """wraps the extension stand-in's functions with HIP event pairs recorded on the launch stream"""
 
-    def __init__(self, torch, ext):
+    def __init__(self, torch, ext, names=None):
+        """names: the functions of `ext` to wrap (default: every *_wrapper of the pointnet2 stand-in)"""
         self.torch, self.ext, self.records, self.saved = torch, ext, [], {}
+        self.names = names
 
     def __enter__(self):
-        for name in [n for n in dir(self.ext) if n.endswith("_wrapper")]:
+        for name in (self.names if self.names is not None else [n for n in dir(self.ext) if n.endswith("_wrapper")]):
             fn = getattr(self.ext, name)
             self.saved[name] = fn
 
-            def timed(*a, _fn=fn, _name=name):
+            def timed(*a, _fn=fn, _name=name, **kw):
                 dev = next(x for x in a if hasattr(x, "is_cuda")).device
                 stream = self.torch.cuda.current_stream(dev)
                 e0 = self.torch.cuda.Event(enable_timing=True)
                 e1 = self.torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
-                r = _fn(*a)
+                r = _fn(*a, **kw)
                 e1.record(stream)
                 self.records.append((_name, a[:5], e0, e1))
                 return r

@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
-"""bench_step.py -- BASELINE.json config 4, the per-rank part: one `rcnn_online` training step of the POINT stream at
-the yaml's shapes (tools/cfgs/LI_Fusion_with_attention_use_ce_loss.yaml) on synthetic KITTI-shaped scenes.
+"""bench_step.py -- BASELINE.json configs 3 and 4: training steps of the model AROUND the hot path at the yaml's shapes
+(tools/cfgs/LI_Fusion_with_attention_use_ce_loss.yaml) on synthetic KITTI-shaped scenes.
 
-    python bench_step.py [--batch 2] [--steps 10] [--warmup 3] [--points 16384]
-    python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 bench_step.py     # scene-parallel, RCCL
+    python bench_step.py --image --rpn-only [--batch 2]       # config 3: two-stream RPN (point + image stream, LI-Fusion) fwd+bwd
+    python bench_step.py --image [--gpus N]                   # config 4: the whole rcnn_online step, 62.7 MB of gradients
+    python bench_step.py                                      # the point stream alone (round-1 figure)
+    python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 bench_step.py --gpus N   # scene-parallel, RCCL
 
 What is timed (forward + backward + SGD step, `--batch` scenes per GPU):
   RPN backbone   4 SA-MSG levels 16384>4096>1024>256>64 + 4 FP levels (lib/net/pointnet2_msg.py:126-196, point stream) and
@@ -12,10 +14,13 @@ What is timed (forward + backward + SGD step, `--batch` scenes per GPU):
   targets        ProposalTargetLayer (IoU, ROI sampling + augmentation, roipool3d 64 x 512 x 133, canonical transform)
   RCNN stage     3 SA levels over 64 ROIs x 512 points per scene (128 > 32 > group-all) and two FC heads
                  (lib/net/rcnn_net.py:43-93, without its loss bookkeeping)
-Every geometry op is this package's HIP path; every dense layer (shared MLPs, batch norm, heads, optimiser) is stock
-PyTorch-ROCm, as the north_star has it. The image stream / LI-Fusion of configs 3-4 is the reference's stock-PyTorch
-territory and is not part of this harness; losses are placeholders (sums of squares) -- the step exercises autograd
-through every op of the hot path at the real shapes, it does not train anything. With N > 1 ranks the model is wrapped
+Every geometry op is this package's HIP path; every dense layer (shared MLPs, batch norm, image convolutions, attention
+fusion, heads, optimiser) is stock PyTorch-ROCm, as the north_star has it. With --image the backbone is the two-stream one
+(epnet_amd/rpn_backbone.py = lib/net/pointnet2_msg.py: four strided conv blocks over a (B,3,384,1280) image ~N(0,1),
+Feature_Gather at the four pyramid levels and at full resolution, attention fusion); pixel coordinates ~U[0,1280)xU[0,384).
+Losses are placeholders (sums of squares) -- the step exercises autograd through every op of the hot path at the real
+shapes, it does not train anything. `ops_share` = HIP-event time inside this package's operators / the step's GPU time,
+from an instrumented pass after the timed one. With N > 1 ranks the model is wrapped
 in DistributedDataParallel: the gradient all-reduce over RCCL / xGMI is the step's only collective (scenes are sharded
 by rank). One JSON line from rank 0.
 """
@@ -39,40 +44,14 @@ RCNN_NPOINTS, RCNN_RADIUS, RCNN_NSAMPLE = [128, 32, None], [0.2, 0.4, 100], [64,
 RCNN_MLPS = [[128, 128, 128], [128, 128, 256], [256, 256, 512]]
 
 
-def build_model(scale=1, rpn_channels=76):
-    """the two-stage point model; scale > 1 divides the pyramid's point counts (small test configurations)"""
+def build_model(scale=1, rpn_channels=76, image=False, sampler="hip"):
+    """the two-stage model; scale > 1 divides the pyramid's point counts (small test configurations); image: the
+    two-stream backbone with LI-Fusion (configs 3 / 4) instead of the point stream alone"""
     import torch
     import torch.nn as nn
-    from epnet_amd import pointnet2_utils as p2u, pytorch_utils as pt_utils
-    from epnet_amd.pointnet2_modules import PointnetFPModule, PointnetSAModule, PointnetSAModuleMSG
+    from epnet_amd import pytorch_utils as pt_utils, rpn_backbone
+    from epnet_amd.pointnet2_modules import PointnetSAModule
     PYRAMID = os.environ.get("EPNET_SA_PYRAMID", "1") != "0"
-
-    class Backbone(nn.Module):   # lib/net/pointnet2_msg.py:126-196, 201-232 without the image branch
-        def __init__(self):
-            super().__init__()
-            self.SA_modules, self.FP_modules = nn.ModuleList(), nn.ModuleList()
-            channel_in, skips = 0, [0]
-            for k in range(len(SA_NPOINTS)):
-                mlps = [[channel_in] + list(m) for m in SA_MLPS[k]]
-                self.SA_modules.append(PointnetSAModuleMSG(npoint=SA_NPOINTS[k] // scale, radii=SA_RADIUS[k], nsamples=SA_NSAMPLE[k],
-                                                           mlps=mlps, use_xyz=True, bn=True))
-                channel_in = sum(m[-1] for m in mlps)
-                skips.append(channel_in)
-            for k in range(len(FP_MLPS)):
-                pre = FP_MLPS[k + 1][-1] if k + 1 < len(FP_MLPS) else channel_in
-                self.FP_modules.append(PointnetFPModule(mlp=[pre + skips[k]] + FP_MLPS[k]))
-
-        def forward(self, xyz):
-            l_xyz, l_feat = [xyz], [None]
-            # every level's sampling up front on a side stream: it runs beside the MLPs instead of between them
-            pyramid = p2u.sample_pyramid(xyz, [sa.npoint for sa in self.SA_modules]) if PYRAMID else [None] * len(self.SA_modules)
-            for sa, pre in zip(self.SA_modules, pyramid):
-                nx, nf, _ = sa(l_xyz[-1], l_feat[-1], presampled=pre)
-                l_xyz.append(nx)
-                l_feat.append(nf)
-            for i in range(-1, -(len(self.FP_modules) + 1), -1):
-                l_feat[i - 1] = self.FP_modules[i](l_xyz[i - 1], l_xyz[i], l_feat[i - 1], l_feat[i])
-            return l_feat[0]
 
     class RCNN(nn.Module):       # lib/net/rcnn_net.py:17-93 (xyz up-layer, merge, SA stack, heads), losses left out
         def __init__(self):
@@ -101,21 +80,27 @@ def build_model(scale=1, rpn_channels=76):
     class TwoStage(nn.Module):
         def __init__(self):
             super().__init__()
-            self.backbone = Backbone()
+            # lib/net/pointnet2_msg.py:126-259 (rpn.py:19: input_channels = 0, the yaml has USE_INTENSITY False)
+            self.backbone = rpn_backbone.Pointnet2MSG(input_channels=0, config=rpn_backbone.BackboneConfig(li_fusion=image),
+                                                      sampler=sampler, scale=scale, pyramid=PYRAMID)
+            self.two_stream = image
             self.rpn_cls = nn.Sequential(pt_utils.Conv1d(128, 128, bn=True), pt_utils.Conv1d(128, 1, activation=None))
             self.rpn_reg = nn.Sequential(pt_utils.Conv1d(128, 128, bn=True), pt_utils.Conv1d(128, rpn_channels, activation=None))
             self.rcnn = RCNN()
             self.layers = None   # (ProposalLayer, ProposalTargetLayer), set by the caller
 
-        def forward(self, xyz, gt_boxes3d, mark=None):
+        def forward(self, xyz, gt_boxes3d, mark=None, image=None, xy=None, rpn_only=False):
             """one forward pass + placeholder loss (the whole step lives in forward so that DistributedDataParallel sees
-            it); returns (loss, dict of outputs)"""
+            it); returns (loss, dict of outputs). image (B,3,H,W) / xy (B,N,2) pixel coordinates (normalised in place, as
+            the reference does) for the two-stream backbone"""
             proposal_layer, target_layer = self.layers
             mark = mark if mark is not None else (lambda name: None)
-            feats = self.backbone(xyz)                                           # (B,128,N)
+            _, feats = self.backbone(xyz, image, xy) if self.two_stream else self.backbone(xyz)   # (B,128,N)
             rpn_cls = self.rpn_cls(feats).transpose(1, 2).contiguous()           # (B,N,1)
             rpn_reg = self.rpn_reg(feats).transpose(1, 2).contiguous()           # (B,N,76)
             mark("rpn")
+            if rpn_only:                                                         # config 3: backbone + heads, dummy loss
+                return rpn_cls.pow(2).mean() + rpn_reg.pow(2).mean(), {"rpn_cls": rpn_cls, "rpn_reg": rpn_reg}
             with torch.no_grad():                                                # lib/net/point_rcnn.py:33-47
                 scores = rpn_cls[:, :, 0].detach()
                 rois, _ = proposal_layer(scores, rpn_reg.detach(), xyz)
@@ -134,10 +119,10 @@ def build_model(scale=1, rpn_channels=76):
     return TwoStage()
 
 
-def run_step(model, layers, xyz, gt_boxes3d, timer=None):
+def run_step(model, layers, xyz, gt_boxes3d, timer=None, image=None, xy=None, rpn_only=False):
     """one forward pass through `model` (plain or DistributedDataParallel-wrapped)"""
     (model.module if hasattr(model, "module") else model).layers = layers
-    return model(xyz, gt_boxes3d, timer)
+    return model(xyz, gt_boxes3d, timer, image, None if xy is None else xy.clone(), rpn_only)
 
 
 def synthetic_batch(batch, points, seed, device):
@@ -157,7 +142,7 @@ def infer(args, model, proposal_layer, xyz):
 
     def stage():
         with torch.no_grad():
-            feats = model.backbone(xyz)
+            _, feats = model.backbone(xyz)
             cls = model.rpn_cls(feats).transpose(1, 2).contiguous()
             reg = model.rpn_reg(feats).transpose(1, 2).contiguous()
             return proposal_layer(cls[:, :, 0].contiguous(), reg, xyz)
@@ -197,6 +182,12 @@ def main():
     ap.add_argument("--infer", action="store_true",
                     help="instead of the training step: inference latency of the RPN stage (backbone, heads, proposal layer) in "
                          "eval mode, eagerly and replayed from a HIP graph (nothing in the stage synchronises with the host)")
+    ap.add_argument("--image", action="store_true",
+                    help="two-stream backbone: (B,3,384,1280) image ~N(0,1), pixel coordinates ~U[0,1280)xU[0,384), LI-Fusion with "
+                         "image attention (BASELINE configs 3 and 4; 15.7 M parameters = 62.7 MB of gradients)")
+    ap.add_argument("--rpn-only", action="store_true", help="config 3: forward + backward of backbone + RPN heads only")
+    ap.add_argument("--sampler", default="hip", choices=["hip", "stock"],
+                    help="point-to-pixel sampler: this package's Feature_Gather or stock torch.gather + grid_sample")
     ap.add_argument("--gpus", type=int, default=1,
                     help="ranks (one per GPU); without a torch.distributed.run environment the ranks are started as child processes")
     ap.add_argument("--launch-check", action="store_true", help="rehearse the N-rank launch only (see bench.py)")
@@ -227,12 +218,17 @@ def main():
             dist.init_process_group(backend)
     torch.manual_seed(1 + rank)
     np.random.seed(1 + rank)
-    model = build_model().to(device)
+    model = build_model(image=args.image, sampler=args.sampler).to(device)
     if world > 1:
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], find_unused_parameters=False)
     opt = torch.optim.SGD(model.parameters(), lr=1e-4, momentum=0.9)
     layers = (pl.ProposalLayer("TRAIN").to(device), ptl.ProposalTargetLayer())
     xyz, gts = synthetic_batch(args.batch, args.points, 100 + 1000 * rank, device)   # every rank its own scenes
+    image = xy = None
+    if args.image:
+        g = torch.Generator().manual_seed(200 + rank)
+        image = torch.randn((args.batch, 3, 384, 1280), generator=g).to(device)                      # lib/datasets/kitti_dataset.py:54
+        xy = (torch.rand((args.batch, args.points, 2), generator=g) * torch.tensor([1280.0, 384.0])).to(device)
 
     if args.infer:
         return infer(args, model.module if hasattr(model, "module") else model, layers[0], xyz)
@@ -248,7 +244,7 @@ def main():
             e.record()
             events.append((name, e))
         opt.zero_grad(set_to_none=True)
-        loss, _ = run_step(model, layers, xyz, gts, mark if timed else None)
+        loss, _ = run_step(model, layers, xyz, gts, mark if timed else None, image, xy, args.rpn_only)
         loss.backward()
         mark("backward")
         opt.step()
@@ -278,13 +274,52 @@ def main():
         t = torch.tensor([elapsed], device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
+    # ---- share of the step spent inside this package's operators: an instrumented pass with a HIP event pair around every
+    # call into the three extension stand-ins (on the stream the call launches on), against the GPU time of the same steps
+    ops_share = None
+    if rank == 0:
+        import contextlib
+        import bench
+        from epnet_amd import iou3d_cuda, pointnet2_cuda, roipool3d_cuda
+        iou_names = [n for n in ("boxes_overlap_bev_gpu", "boxes_iou_bev_gpu", "boxes_iou3d_fused_gpu", "boxes_iou3d_pairs_gpu",
+                                 "aug_roi_by_noise_gpu", "rpn_proposals_gpu", "nms_device", "nms_normal_device")]
+        timers = [bench.OpTimer(torch, pointnet2_cuda), bench.OpTimer(torch, iou3d_cuda, iou_names),
+                  bench.OpTimer(torch, roipool3d_cuda, ["forward"])]
+        reps = max(2, min(5, args.steps))
+        with contextlib.ExitStack() as stack:
+            for t in timers:
+                stack.enter_context(t)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(reps):
+                one(False)
+            e1.record()
+            torch.cuda.synchronize()
+        per_op = {}
+        for t in timers:
+            for name, _head, a, b_ in t.records:
+                per_op[name] = per_op.get(name, 0.0) + a.elapsed_time(b_) / reps
+        ops_ms = sum(per_op.values())
+        step_gpu_ms = e0.elapsed_time(e1) / reps
+        ops_share = {"ops_ms_per_step": round(ops_ms, 3), "instrumented_step_ms": round(step_gpu_ms, 3),
+                     "share": round(ops_ms / step_gpu_ms, 4),
+                     "per_op_ms": {k: round(v, 3) for k, v in sorted(per_op.items(), key=lambda kv: -kv[1])},
+                     "note": "sum of HIP-event durations of every call into the pointnet2 / iou3d / roipool3d stand-ins "
+                             "(calls on the side stream overlap the dense layers, so the share is of GPU work, not of wall time)"}
     if rank == 0:
         n_param = sum(p.numel() for p in model.parameters())
-        print(json.dumps({"metric": "rcnn_online point-stream training step (BASELINE config 4, per-rank part)", "n_gpus": world,
+        what = ("two-stream RPN fwd+bwd (BASELINE config 3)" if (args.image and args.rpn_only) else
+                "rcnn_online training step, two-stream model (BASELINE config 4)" if args.image else
+                "RPN fwd+bwd, point stream only" if args.rpn_only else
+                "rcnn_online point-stream training step (BASELINE config 4 without the image stream)")
+        print(json.dumps({"metric": what, "n_gpus": world, "image_stream": bool(args.image), "rpn_only": bool(args.rpn_only),
+                          "sampler": args.sampler, "ops_share": ops_share,
                           "scenes_per_gpu": args.batch, "points_per_scene": args.points, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(elapsed / args.steps * 1e3, 3),
                           "ms_per_step_median": round(sorted(per_step)[len(per_step) // 2] * 1e3, 3),
                           "ms_per_step_max": round(max(per_step) * 1e3, 3),
+                          "ms_per_step_all": [round(x * 1e3, 2) for x in per_step],
                           "scenes_per_s": round(world * args.batch * args.steps / elapsed, 2),
                           "phase_ms": {k: round(v / args.steps, 3) for k, v in phases.items()},
                           "parameters": n_param, "grad_allreduce_MB": round(n_param * 4 / 1e6, 1) if world > 1 else 0,

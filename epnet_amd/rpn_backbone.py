@@ -1,0 +1,191 @@
+"""The two-stream RPN backbone of EPNet -- point stream (4 SA-MSG + 4 FP levels) beside an image stream (4 strided
+conv blocks) with LI-Fusion at every pyramid level -- as the CALLER of the hot path for BASELINE config 3 / 4
+(reference: lib/net/pointnet2_msg.py:16-104 layers, :126-196 construction, :201-259 forward).
+
+This is measurement scaffolding, not the product: every dense layer here is stock PyTorch-ROCm, exactly as the
+north_star has it. What belongs to the hot path is what the layers are glued together with -- the SA / FP modules
+(``epnet_amd.pointnet2_modules``) and the point-to-pixel sampler ``Feature_Gather`` consuming the FPS indices
+(``epnet_amd.li_fusion``). Sub-module and parameter names follow the reference so that its checkpoints load
+(``SA_modules.*``, ``Img_Block.*``, ``Fusion_Conv.*.IA_Layer.*``, ``DeConv.*``, ``image_fusion_conv``, ``image_fusion_bn``,
+``final_fusion_img_point.*``, ``FP_modules.*``); the configuration is an explicit argument instead of the reference's
+global ``cfg`` (defaults = tools/cfgs/LI_Fusion_with_attention_use_ce_loss.yaml:24-36, 56-64).
+
+``sampler``: "hip" = this package's ``Feature_Gather`` with the xy gather over the FPS indices folded in; "stock" = the
+reference's own two steps, ``torch.gather`` + ``torch.nn.functional.grid_sample`` (``align_corners=True``: the
+reference was written for torch <= 1.2, which behaved that way) -- the yardstick of tests/test_two_stream.py.
+"""
+from dataclasses import dataclass, field
+from typing import List
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import li_fusion, pointnet2_utils
+from .pointnet2_modules import PointnetFPModule, PointnetSAModuleMSG
+
+
+@dataclass
+class BackboneConfig:
+    """RPN.SA_CONFIG / RPN.FP_MLPS / LI_FUSION of the yaml (:24-36, :56-64)"""
+    npoints: List[int] = field(default_factory=lambda: [4096, 1024, 256, 64])
+    radius: List[List[float]] = field(default_factory=lambda: [[0.1, 0.5], [0.5, 1.0], [1.0, 2.0], [2.0, 4.0]])
+    nsample: List[List[int]] = field(default_factory=lambda: [[16, 32], [16, 32], [16, 32], [16, 32]])
+    mlps: List[List[List[int]]] = field(default_factory=lambda: [[[16, 16, 32], [32, 32, 64]], [[64, 64, 128], [64, 96, 128]],
+                                                                 [[128, 196, 256], [128, 196, 256]], [[256, 256, 512], [256, 384, 512]]])
+    fp_mlps: List[List[int]] = field(default_factory=lambda: [[128, 128], [256, 256], [512, 512], [512, 512]])
+    use_bn: bool = True
+    li_fusion: bool = True
+    attention: bool = True                     # LI_FUSION.ADD_Image_Attention
+    img_channels: List[int] = field(default_factory=lambda: [3, 64, 128, 256, 512])
+    point_channels: List[int] = field(default_factory=lambda: [96, 256, 512, 1024])
+    deconv_reduce: List[int] = field(default_factory=lambda: [16, 16, 16, 16])
+    deconv_kernels: List[int] = field(default_factory=lambda: [2, 4, 8, 16])
+    img_features_channel: int = 128
+    image_size: List[float] = field(default_factory=lambda: [1280.0, 384.0])     # (width, height) the pixel coordinates refer to (:205)
+
+
+class BasicBlock(nn.Module):
+    """conv3x3(stride) - BN - ReLU - conv3x3(2 * stride): halves the resolution (:16-33)"""
+
+    def __init__(self, inplanes, outplanes, stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, outplanes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(outplanes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(outplanes, outplanes, kernel_size=3, stride=2 * stride, padding=1, bias=False)
+
+    def forward(self, x):
+        return self.conv2(self.relu(self.bn1(self.conv1(x))))
+
+
+class Fusion_Conv(nn.Module):
+    """[point ; image] -> 1x1 conv - BN - ReLU (:35-49)"""
+
+    def __init__(self, inplanes, outplanes):
+        super().__init__()
+        self.conv1 = nn.Conv1d(inplanes, outplanes, 1)
+        self.bn1 = nn.BatchNorm1d(outplanes)
+
+    def forward(self, point_features, img_features):
+        return F.relu(self.bn1(self.conv1(torch.cat([point_features, img_features], dim=1))))
+
+
+class IA_Layer(nn.Module):
+    """per-point attention on the sampled image features, from both streams (:53-83)"""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.ic, self.pc = channels
+        rc = self.pc // 4
+        self.conv1 = nn.Sequential(nn.Conv1d(self.ic, self.pc, 1), nn.BatchNorm1d(self.pc), nn.ReLU())
+        self.fc1 = nn.Linear(self.ic, rc)
+        self.fc2 = nn.Linear(self.pc, rc)
+        self.fc3 = nn.Linear(rc, 1)
+
+    def forward(self, img_feas, point_feas):
+        batch = img_feas.size(0)
+        ri = self.fc1(img_feas.transpose(1, 2).reshape(-1, self.ic))
+        rp = self.fc2(point_feas.transpose(1, 2).reshape(-1, self.pc))
+        att = torch.sigmoid(self.fc3(torch.tanh(ri + rp))).view(batch, 1, -1)
+        return self.conv1(img_feas) * att
+
+
+class Atten_Fusion_Conv(nn.Module):
+    """attention-weighted image features concatenated to the point features, then 1x1 conv - BN - ReLU (:86-104)"""
+
+    def __init__(self, inplanes_I, inplanes_P, outplanes):
+        super().__init__()
+        self.IA_Layer = IA_Layer(channels=[inplanes_I, inplanes_P])
+        self.conv1 = nn.Conv1d(inplanes_P + inplanes_P, outplanes, 1)
+        self.bn1 = nn.BatchNorm1d(outplanes)
+
+    def forward(self, point_features, img_features):
+        weighted = self.IA_Layer(img_features, point_features)
+        return F.relu(self.bn1(self.conv1(torch.cat([point_features, weighted], dim=1))))
+
+
+def stock_feature_gather(feature_map, xy):
+    """the reference's ``Feature_Gather`` (:107-120) on the stock op, with the behaviour its torch version had"""
+    return F.grid_sample(feature_map, xy.unsqueeze(1), mode="bilinear", padding_mode="zeros", align_corners=True).squeeze(2)
+
+
+class Pointnet2MSG(nn.Module):
+    def __init__(self, input_channels=0, use_xyz=True, config: BackboneConfig = None, sampler="hip", scale=1, pyramid=True):
+        """scale > 1 divides the pyramid's point counts (small test configurations); pyramid: sample all levels up front on
+        a side stream (pointnet2_utils.sample_pyramid)"""
+        super().__init__()
+        cfg = self.cfg = config or BackboneConfig()
+        assert sampler in ("hip", "stock")
+        self.sampler, self.pyramid = sampler, pyramid
+        self.SA_modules = nn.ModuleList()
+        channel_in, skips = input_channels, [input_channels]
+        for k in range(len(cfg.npoints)):
+            specs = [[channel_in] + list(m) for m in cfg.mlps[k]]
+            self.SA_modules.append(PointnetSAModuleMSG(npoint=cfg.npoints[k] // scale, radii=cfg.radius[k], nsamples=cfg.nsample[k],
+                                                       mlps=specs, use_xyz=use_xyz, bn=cfg.use_bn))
+            channel_in = sum(m[-1] for m in cfg.mlps[k])
+            skips.append(channel_in)
+        if cfg.li_fusion:
+            self.Img_Block, self.Fusion_Conv, self.DeConv = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+            for i in range(len(cfg.img_channels) - 1):
+                ic, pc = cfg.img_channels[i + 1], cfg.point_channels[i]
+                self.Img_Block.append(BasicBlock(cfg.img_channels[i], ic, stride=1))
+                self.Fusion_Conv.append(Atten_Fusion_Conv(ic, pc, pc) if cfg.attention else Fusion_Conv(ic + pc, pc))
+                self.DeConv.append(nn.ConvTranspose2d(ic, cfg.deconv_reduce[i], kernel_size=cfg.deconv_kernels[i],
+                                                      stride=cfg.deconv_kernels[i]))
+            quarter = cfg.img_features_channel // 4
+            self.image_fusion_conv = nn.Conv2d(sum(cfg.deconv_reduce), quarter, kernel_size=1)
+            self.image_fusion_bn = nn.BatchNorm2d(quarter)
+            self.final_fusion_img_point = (Atten_Fusion_Conv(quarter, cfg.img_features_channel, cfg.img_features_channel)
+                                           if cfg.attention else Fusion_Conv(cfg.img_features_channel + quarter, cfg.img_features_channel))
+        self.FP_modules = nn.ModuleList()
+        for k in range(len(cfg.fp_mlps)):
+            pre = cfg.fp_mlps[k + 1][-1] if k + 1 < len(cfg.fp_mlps) else channel_in
+            self.FP_modules.append(PointnetFPModule(mlp=[pre + skips[k]] + list(cfg.fp_mlps[k])))
+
+    @staticmethod
+    def _break_up_pc(pc):
+        xyz = pc[..., 0:3].contiguous()
+        features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
+        return xyz, features
+
+    def _sample_image(self, feature_map, xy, fps_idx):
+        """image features at the pixels of the points `fps_idx` picks from `xy` (:214-218) -> ((B,C,M), xy of the M points)"""
+        if self.sampler == "hip":
+            return li_fusion.Feature_Gather(feature_map, xy, fps_idx)
+        picked = torch.gather(xy, 1, fps_idx.long().unsqueeze(-1).repeat(1, 1, 2))
+        return stock_feature_gather(feature_map, picked), picked
+
+    def forward(self, pointcloud, image=None, xy=None):
+        """pointcloud (B,N,3+C), image (B,3,H,W), xy (B,N,2) pixel coordinates -- normalised to [-1,1] IN PLACE, as the
+        reference does (:205-208): hand over a tensor you do not need again. Returns (xyz (B,N,3), features (B,128,N))"""
+        cfg = self.cfg
+        xyz, features = self._break_up_pc(pointcloud)
+        l_xyz, l_feat = [xyz], [features]
+        fuse = cfg.li_fusion
+        if fuse:
+            xy[:, :, 0] = xy[:, :, 0] / (cfg.image_size[0] - 1.0) * 2.0 - 1.0
+            xy[:, :, 1] = xy[:, :, 1] / (cfg.image_size[1] - 1.0) * 2.0 - 1.0
+            l_xy, img = [xy], [image]
+        # furthest point sampling depends on coordinates only: every level's sampling up front, beside the image convolutions
+        pre = (pointnet2_utils.sample_pyramid(xyz, [sa.npoint for sa in self.SA_modules]) if (self.pyramid and xyz.is_cuda)
+               else [None] * len(self.SA_modules))
+        for i, sa in enumerate(self.SA_modules):
+            li_xyz, li_feat, li_index = sa(l_xyz[i], l_feat[i], presampled=pre[i])
+            if fuse:
+                fmap = self.Img_Block[i](img[i])
+                sampled, li_xy = self._sample_image(fmap, l_xy[i], li_index)
+                li_feat = self.Fusion_Conv[i](li_feat, sampled)
+                l_xy.append(li_xy)
+                img.append(fmap)
+            l_xyz.append(li_xyz)
+            l_feat.append(li_feat)
+        for i in range(-1, -(len(self.FP_modules) + 1), -1):
+            l_feat[i - 1] = self.FP_modules[i](l_xyz[i - 1], l_xyz[i], l_feat[i - 1], l_feat[i])
+        if fuse:
+            up = torch.cat([self.DeConv[i](img[i + 1]) for i in range(len(self.DeConv))], dim=1)
+            img_fusion = F.relu(self.image_fusion_bn(self.image_fusion_conv(up)))
+            full = (li_fusion.Feature_Gather(img_fusion, xy) if self.sampler == "hip" else stock_feature_gather(img_fusion, xy))
+            l_feat[0] = self.final_fusion_img_point(l_feat[0], full)
+        return l_xyz[0], l_feat[0]

@@ -38,6 +38,37 @@ def test_rcnn_online_step_forward_backward(hiplib):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rpn_only", [True, False])
+def test_two_stream_step_forward_backward(hiplib, rpn_only):
+    """BASELINE configs 3 (rpn_only) and 4 with the image stream, at a reduced size: every parameter of the two-stream
+    model -- image blocks, attention fusion, deconvolutions included -- receives a finite gradient through the HIP sampler"""
+    import bench_step
+    from epnet_amd import proposal_layer as pl, proposal_target_layer as ptl
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    np.random.seed(0)
+    model = bench_step.build_model(scale=8, image=True).to(dev)
+    layers = (pl.ProposalLayer("TRAIN").to(dev), ptl.ProposalTargetLayer())
+    xyz, gts = bench_step.synthetic_batch(2, 2048, 7, dev)
+    g = torch.Generator().manual_seed(1)
+    image = torch.randn((2, 3, 96, 320), generator=g).to(dev)
+    xy = (torch.rand((2, 2048, 2), generator=g) * torch.tensor([1280.0, 384.0])).to(dev)
+    xy_before = xy.clone()
+    loss, out = bench_step.run_step(model, layers, xyz, gts, None, image, xy, rpn_only)
+    loss.backward()
+    assert torch.equal(xy, xy_before)                       # run_step hands the model a copy: the model normalises in place
+    assert np.isfinite(float(loss.detach()))
+    skip = ("rcnn.",) if rpn_only else ()
+    missing = [n for n, p in model.named_parameters() if p.grad is None and not n.startswith(skip)] if skip else \
+        [n for n, p in model.named_parameters() if p.grad is None]
+    assert not missing, missing
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    img_w = dict(model.named_parameters())["backbone.Img_Block.0.conv1.weight"]
+    assert float(img_w.grad.abs().sum()) > 0
+    assert sum(p.numel() for p in model.backbone.parameters()) == 14131949
+
+
+@pytest.mark.gpu
 def test_rpn_stage_records_into_a_hip_graph(hiplib):
     """backbone (sampling pyramid on a side stream, SA / FP modules with folded first layers and the pool kernel), heads and
     proposal layer in eval mode: nothing synchronises with the host, so the stage captures into a HIP graph whose replay
@@ -52,7 +83,7 @@ def test_rpn_stage_records_into_a_hip_graph(hiplib):
 
     def stage():
         with torch.no_grad():
-            feats = model.backbone(xyz)
+            _, feats = model.backbone(xyz)
             cls = model.rpn_cls(feats).transpose(1, 2).contiguous()
             reg = model.rpn_reg(feats).transpose(1, 2).contiguous()
             return proposal_layer_out(cls, reg)

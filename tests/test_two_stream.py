@@ -1,0 +1,148 @@
+"""BASELINE config 3 -- the two-stream RPN backbone (point stream + image stream + LI-Fusion) forward and backward.
+
+Pinned three ways:
+  * names / shapes / parameter count of ``epnet_amd.rpn_backbone.Pointnet2MSG`` against the reference's own class at the
+    full yaml configuration (tests/golden/two_stream_names.json);
+  * a reduced configuration against what the reference's own ``lib/net/pointnet2_msg.py`` computed with the same seeded
+    state_dict -- training-mode output, gradients w.r.t. the image and parameters of every part, eval-mode output
+    (tests/golden/two_stream.npz, made by tests/golden/make_golden_two_stream.py); on the CPU through oracle-backed
+    extension stand-ins (host logic), on the GPU through the HIP kernels;
+  * on the GPU at the FULL size (16384 points, 384 x 1280 image): this package's sampler against the same model on stock
+    ``grid_sample(align_corners=True)`` + ``torch.gather`` -- outputs and all gradients.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, golden
+
+
+def small_config():
+    from epnet_amd.rpn_backbone import BackboneConfig
+    fx = golden("two_stream.npz")
+    c = json.loads(bytes(fx["config"]).decode())
+    return BackboneConfig(npoints=c["npoints"], radius=c["radius"], nsample=c["nsample"], mlps=c["mlps"], fp_mlps=c["fp_mlps"],
+                          img_channels=c["img_channels"], point_channels=c["point_channels"], deconv_reduce=c["deconv_reduce"],
+                          deconv_kernels=c["deconv_kernels"], img_features_channel=c["img_features_channel"])
+
+
+def load_small(sampler, device="cpu"):
+    from epnet_amd.rpn_backbone import Pointnet2MSG
+    fx = golden("two_stream.npz")
+    model = Pointnet2MSG(input_channels=0, config=small_config(), sampler=sampler)
+    sd = {k[4:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("sd__")}
+    assert sorted(sd) == sorted(model.state_dict().keys())       # the reference's names, key for key
+    model.load_state_dict(sd)
+    return model.to(device), fx
+
+
+def run_small(model, fx, device, rtol, atol):
+    pts = torch.from_numpy(fx["pts"]).to(device)
+    xy = torch.from_numpy(fx["xy"]).to(device)
+    image = torch.from_numpy(fx["image"]).to(device).requires_grad_(True)
+    model.train()
+    xyz, feats = model(pts.clone(), image, xy.clone())
+    assert torch.equal(xyz.cpu(), torch.from_numpy(fx["pts"]))
+    np.testing.assert_allclose(feats.detach().cpu().numpy(), fx["features"], rtol=rtol, atol=atol)
+    (feats * torch.from_numpy(fx["probe"]).to(device)).sum().backward()
+    np.testing.assert_allclose(image.grad.cpu().numpy(), fx["grad__image"], rtol=10 * rtol, atol=10 * atol)
+    params = dict(model.named_parameters())
+    names = [k[6:] for k in fx.files if k.startswith("grad__") and k != "grad__image"]
+    assert len(names) >= 10
+    for name in names:
+        want = fx["grad__" + name]
+        scale = max(1.0, float(np.abs(want).max()))
+        np.testing.assert_allclose(params[name].grad.cpu().numpy(), want, rtol=10 * rtol, atol=10 * atol * scale, err_msg=name)
+    # eval mode, from the same initial state (the training pass moved the running statistics)
+    model.load_state_dict({k[4:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("sd__")})
+    model.eval()
+    with torch.no_grad():
+        _, feats_eval = model(pts.clone(), image.detach().clone(), xy.clone())
+    np.testing.assert_allclose(feats_eval.cpu().numpy(), fx["features_eval"], rtol=rtol, atol=atol)
+
+
+def test_names_shapes_and_size_match_the_reference_model():
+    from epnet_amd.rpn_backbone import Pointnet2MSG
+    ref = json.load(open(os.path.join(GOLDEN, "two_stream_names.json")))
+    model = Pointnet2MSG(input_channels=0)
+    mine = {k: list(v.shape) for k, v in model.state_dict().items()}
+    assert mine == ref["state_dict"]
+    assert list(mine) == sorted(mine, key=list(mine).index) and len(mine) == 335
+    n_param = sum(p.numel() for p in model.parameters())
+    assert n_param == ref["parameters"] == 14131949           # 56.5 MB of the step's 62.7 MB gradient volume
+
+
+@pytest.mark.parametrize("sampler", ["stock", "hip"])
+def test_reduced_model_reproduces_the_reference_on_cpu(monkeypatch, oracle, sampler):
+    """host logic: the forward's wiring (xy normalisation in place, FPS-index gather of the pixel coordinates, fusion
+    order, FP walk, final full-resolution fusion) on oracle-backed extension stand-ins"""
+    import oracle_ext
+    from epnet_amd import pointnet2_cuda
+    p2, _, _ = oracle_ext.make_modules()
+    for name, fn in vars(p2).items():
+        if callable(fn):
+            monkeypatch.setattr(pointnet2_cuda, name, fn)
+    model, fx = load_small(sampler)
+    run_small(model, fx, "cpu", rtol=2e-4, atol=2e-5)
+
+
+def test_forward_normalises_xy_in_place_like_the_reference(monkeypatch, oracle):
+    import oracle_ext
+    from epnet_amd import pointnet2_cuda
+    p2, _, _ = oracle_ext.make_modules()
+    for name, fn in vars(p2).items():
+        if callable(fn):
+            monkeypatch.setattr(pointnet2_cuda, name, fn)
+    model, fx = load_small("stock")
+    xy = torch.from_numpy(fx["xy"]).clone()
+    with torch.no_grad():
+        model.eval()(torch.from_numpy(fx["pts"]), torch.from_numpy(fx["image"]), xy)
+    want = torch.from_numpy(fx["xy"]).clone()
+    want[:, :, 0] = want[:, :, 0] / 1279.0 * 2.0 - 1.0            # lib/net/pointnet2_msg.py:205-208
+    want[:, :, 1] = want[:, :, 1] / 383.0 * 2.0 - 1.0
+    assert torch.equal(xy, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sampler", ["hip", "stock"])
+def test_reduced_model_reproduces_the_reference_on_gpu(hiplib, sampler):
+    model, fx = load_small(sampler, "cuda:0")
+    run_small(model, fx, "cuda:0", rtol=5e-4, atol=5e-5)
+
+
+@pytest.mark.gpu
+def test_full_size_two_stream_backbone_against_stock_sampler(hiplib):
+    """config 3 at its real shapes (2 scenes x 16384 points, 384 x 1280 image), forward + backward: the model on this
+    package's point-to-pixel sampler against the same weights on stock grid_sample(align_corners=True) + torch.gather.
+    Identical FPS indices feed both, so the comparison isolates the sampler inside the whole network."""
+    from epnet_amd import synth
+    from epnet_amd.rpn_backbone import Pointnet2MSG
+    dev = "cuda:0"
+    torch.manual_seed(11)
+    hip = Pointnet2MSG(input_channels=0, sampler="hip").to(dev)
+    stock = Pointnet2MSG(input_channels=0, sampler="stock").to(dev)
+    stock.load_state_dict(hip.state_dict())
+    b, n = 2, 16384
+    g = torch.Generator().manual_seed(12)
+    pts = synth.scenes("kitti", b, n, seed=13).to(dev)
+    image = torch.randn((b, 3, 384, 1280), generator=g).to(dev)
+    xy = (torch.rand((b, n, 2), generator=g) * torch.tensor([1280.0, 384.0])).to(dev)
+    probe = torch.randn((b, 128, n), generator=g).to(dev) / (b * n)
+    results = []
+    for model in (hip, stock):
+        model.train()
+        img = image.clone().requires_grad_(True)
+        xyz, feats = model(pts.clone(), img, xy.clone())
+        assert tuple(feats.shape) == (b, 128, n) and torch.equal(xyz, pts)
+        (feats * probe).sum().backward()
+        results.append((feats.detach(), img.grad, {k: p.grad for k, p in model.named_parameters()}))
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+    (f_hip, gi_hip, gp_hip), (f_stock, gi_stock, gp_stock) = results
+    torch.testing.assert_close(f_hip, f_stock, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(gi_hip, gi_stock, rtol=1e-3, atol=1e-4 * float(gi_stock.abs().max()))
+    for k in gp_stock:
+        tol = 1e-4 * max(1e-6, float(gp_stock[k].abs().max()))
+        torch.testing.assert_close(gp_hip[k], gp_stock[k], rtol=1e-3, atol=tol, msg=lambda m, k=k: "%s: %s" % (k, m))
