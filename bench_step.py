@@ -255,8 +255,12 @@ def main():
                 phases[name] = phases.get(name, 0.0) + a.elapsed_time(b)
         return float(loss.detach()) if timed else None
 
-    for _ in range(args.warmup):
+    t_w = time.perf_counter()
+    for k in range(args.warmup):
         one(False)
+        if k == 0 and rank == 0:
+            torch.cuda.synchronize()
+            print("first step (kernel selection of the dense layers included): %.1f s" % (time.perf_counter() - t_w), file=sys.stderr, flush=True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

@@ -43,10 +43,6 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
     return v;
 }
 
-// lists longer than this are summed by a whole wave instead of their owner thread (inverse-index gradients)
-constexpr int kLongList = 48;
-constexpr int kLongQueue = 512;
-
 }  // namespace epnet
 
 #define EPNET_REQUIRE(cond) \

@@ -16,6 +16,7 @@
 //             reference), so gradients are compared to 1e-5, not bit-for-bit.
 #include "common.h"
 #include "spatial.h"
+#include "runsum.h"
 
 namespace epnet {
 
@@ -437,144 +438,11 @@ static int launch_gather_rows(int b, int c, int n, long long p, const float *poi
     return check_launch(what);
 }
 
-// ---- scatter-add without atomics: inverse index (CSR) + per-target sums --------------------------------------
-// LDS float atomics retire ~1 lane per 3 cycles per CU on this chip, which made the LDS-accumulating kernels
-// above atomic-bound. With caller scratch the scatter is inverted instead: csr_build_kernel groups the
-// positions q by their target idx[q] (counting sort, one workgroup per scene); scatter_rows_csr_kernel then
-// stages whole grad_out rows in LDS with coalesced loads and gives every target j to one thread that sums
-// its list out of LDS -- no atomics, coalesced global traffic only. The order of the terms inside a list is
-// whatever the counting sort produced (the reference's atomicAdd order is unspecified as well).
-constexpr int kCsrThreads = 1024;
-constexpr int kCsrMaxTargets = 16384;
-
-// offsets: (n+1) ints, perm: p ints, per scene. The key of position t is idx[t], or with key_div > 0
-// idx[t] + (t / key_div) * key_mul (positions partitioned into runs of key_div, each run with its own key range).
-__global__ __launch_bounds__(kCsrThreads) void csr_build_kernel(int n, int p, const int *__restrict__ idx,
-                                                                int *__restrict__ offsets, int *__restrict__ perm,
-                                                                int key_div, int key_mul) {
-    extern __shared__ int s_hist[];
-    __shared__ int s_part[16];
-    const int q = threadIdx.x, lane = q & 63, wave = q >> 6;
-    idx += (size_t)blockIdx.x * p;
-    offsets += (size_t)blockIdx.x * (n + 1);
-    perm += (size_t)blockIdx.x * p;
-    const int per = (n + kCsrThreads - 1) / kCsrThreads;  // bins per thread
-    const int words = kCsrThreads * (per + 1);
-    for (int i = q; i < words; i += kCsrThreads) s_hist[i] = 0;
-    __syncthreads();
-    // bin j lives at j + j / per: thread-contiguous runs fall on distinct banks
-    for (int t = q; t < p; t += kCsrThreads) {
-        const int j = idx[t] + (key_div ? (t / key_div) * key_mul : 0);
-        atomicAdd(&s_hist[j + j / per], 1);
-    }
-    __syncthreads();
-    int sum = 0;
-    for (int i = 0; i < per; ++i) sum += s_hist[q * (per + 1) + i];
-    const int incl = wave_inclusive_scan(sum);
-    if (lane == 63) s_part[wave] = incl;
-    __syncthreads();
-    int base = incl - sum;
-    for (int w = 0; w < wave; ++w) base += s_part[w];
-    for (int i = 0; i < per; ++i) {
-        const int j = q * per + i;
-        const int at = q * (per + 1) + i;
-        const int cnt = s_hist[at];
-        s_hist[at] = base;
-        if (j < n) offsets[j] = base;
-        base += cnt;
-    }
-    if (q == kCsrThreads - 1) offsets[n] = p;
-    __syncthreads();
-    for (int t = q; t < p; t += kCsrThreads) {
-        const int j = idx[t] + (key_div ? (t / key_div) * key_mul : 0);
-        perm[atomicAdd(&s_hist[j + j / per], 1)] = t;
-    }
-}
-
-template <int ROWS>
-__global__ __launch_bounds__(kCsrThreads) void scatter_rows_csr_kernel(int c, int n, int p, size_t gstride,
-                                                                       const float *__restrict__ grad_out,
-                                                                       const int *__restrict__ offsets,
-                                                                       const int *__restrict__ perm,
-                                                                       float *__restrict__ grad_points) {
-    extern __shared__ float s_go[];  // ROWS * p floats
-    const int bs = blockIdx.y;
-    const int c0 = blockIdx.x * ROWS;
-    const int nr = min(ROWS, c - c0);
-    const float *go = grad_out + (size_t)bs * gstride + (size_t)c0 * p;
-    const int total = nr * p;
-    if ((p & 3) == 0 && ((uintptr_t)go & 15) == 0) {
-        const float4 *src4 = reinterpret_cast<const float4 *>(go);
-        float4 *dst4 = reinterpret_cast<float4 *>(s_go);
-        for (int e = threadIdx.x; e < total / 4; e += kCsrThreads) dst4[e] = src4[e];
-    } else {
-        for (int e = threadIdx.x; e < total; e += kCsrThreads) s_go[e] = go[e];
-    }
-    __syncthreads();
-    offsets += (size_t)bs * (n + 1);
-    perm += (size_t)bs * p;
-    float *gp = grad_points + ((size_t)bs * c + c0) * n;
-    // list lengths are very uneven on real neighbour lists (ball-query padding repeats one index up to nsample
-    // times): a thread sums its own short lists, lists longer than kLongList are queued and summed by whole waves
-    __shared__ int s_long[kLongQueue];
-    __shared__ int s_nlong;
-    if (threadIdx.x == 0) s_nlong = 0;
-    __syncthreads();
-    for (int j = threadIdx.x; j < n; j += kCsrThreads) {
-        const int beg = offsets[j], end = offsets[j + 1];
-        if (end - beg > kLongList) {
-            const int slot = atomicAdd(&s_nlong, 1);
-            if (slot < kLongQueue) {
-                s_long[slot] = j;
-                continue;
-            }
-        }
-        float acc[ROWS];
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
-        for (int t = beg; t < end; ++t) {
-            const int q = perm[t];
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r)
-                if (r < nr) acc[r] += s_go[r * p + q];
-        }
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r)
-            if (r < nr) gp[(size_t)r * n + j] += acc[r];
-    }
-    __syncthreads();
-    const int nlong = min(s_nlong, kLongQueue);
-    const int lane = threadIdx.x & 63;
-    for (int li = threadIdx.x >> 6; li < nlong; li += kCsrThreads / 64) {
-        const int j = s_long[li];
-        const int beg = offsets[j], end = offsets[j + 1];
-        float acc[ROWS];
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
-        for (int t = beg + lane; t < end; t += 64) {
-            const int q = perm[t];
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r)
-                if (r < nr) acc[r] += s_go[r * p + q];
-        }
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-            const float sum = wave_sum_f32(acc[r]);
-            if (r < nr && lane == 0) gp[(size_t)r * n + j] += sum;
-        }
-    }
-}
-
-int csr_build_launch(int b, int n, int p, const int *idx, int *offsets, int *perm, hipStream_t s, int key_div, int key_mul) {
-    const int per = (n + kCsrThreads - 1) / kCsrThreads;
-    hipLaunchKernelGGL(csr_build_kernel, dim3(b), dim3(kCsrThreads), (size_t)kCsrThreads * (per + 1) * sizeof(int), s, n, p, idx,
-                       offsets, perm, key_div, key_mul);
-    return check_launch("csr_build");
-}
-
+// ---- scatter-add without atomics (runsum.h): the positions grouped by target once, then equal shares of the sorted
+// entries summed per thread out of LDS-staged grad_out rows
 static size_t scatter_ws_bytes(int b, int n, long long p) {
-    if (b <= 0 || n <= 0 || n > kCsrMaxTargets || p <= 0 || p * 4 > 128 * 1024) return 0;
-    return (size_t)b * ((size_t)(n + 1) + (size_t)p) * sizeof(int);
+    if (b <= 0 || !runsum::usable(n, p, p)) return 0;
+    return runsum::workspace_bytes(b, p, false);
 }
 
 static int launch_scatter_rows_csr(int b, int c, int n, long long p, const float *grad_out, const int *idx,
@@ -583,23 +451,8 @@ static int launch_scatter_rows_csr(int b, int c, int n, long long p, const float
     if (gstride == 0) gstride = (size_t)c * (size_t)p;
     if (b == 0 || c == 0 || p == 0 || n == 0) return EPNET_OK;
     if (!(grad_out && idx && grad_points && workspace)) return EPNET_EINVAL;
-    if (workspace_bytes < scatter_ws_bytes(b, n, p)) return EPNET_ENOMEM;
-    if (b > 65535) return EPNET_ELIMIT;
-    int *offsets = (int *)workspace;
-    int *perm = offsets + (size_t)b * (n + 1);
-    int rc = csr_build_launch(b, n, (int)p, idx, offsets, perm, s);
-    if (rc) return rc;
-    const int fit = (int)((128 * 1024) / (p * 4));  // rows of grad_out that fit the LDS budget
-    const int rows = fit >= 8 ? 8 : fit >= 4 ? 4 : fit >= 2 ? 2 : 1;
-    const size_t lds = (size_t)rows * p * 4;
-    dim3 grid(div_up(c, rows), b);
-    switch (rows) {
-        case 8: hipLaunchKernelGGL(scatter_rows_csr_kernel<8>, grid, dim3(kCsrThreads), lds, s, c, n, (int)p, gstride, grad_out, offsets, perm, grad_points); break;
-        case 4: hipLaunchKernelGGL(scatter_rows_csr_kernel<4>, grid, dim3(kCsrThreads), lds, s, c, n, (int)p, gstride, grad_out, offsets, perm, grad_points); break;
-        case 2: hipLaunchKernelGGL(scatter_rows_csr_kernel<2>, grid, dim3(kCsrThreads), lds, s, c, n, (int)p, gstride, grad_out, offsets, perm, grad_points); break;
-        default: hipLaunchKernelGGL(scatter_rows_csr_kernel<1>, grid, dim3(kCsrThreads), lds, s, c, n, (int)p, gstride, grad_out, offsets, perm, grad_points); break;
-    }
-    return check_launch(what);
+    return runsum::launch<false>(b, c, n, (int)p, 1, (int)p, grad_out, gstride, idx, nullptr, grad_points, workspace,
+                                 workspace_bytes, s, what);
 }
 
 static int launch_scatter_rows(int b, int c, int n, long long p, const float *grad_out, const int *idx,
@@ -754,7 +607,7 @@ extern "C" int epnet_group_points_grad_ws(int b, int c, int n, int npoints, int 
                                           epnet_stream_t stream) {
     EPNET_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0 && nsample >= 0);
     const long long p = (long long)npoints * nsample;
-    if (scatter_ws_bytes(b, n, p) == 0)
+    if (scatter_ws_bytes(b, n, p) == 0 || ((uintptr_t)grad_out & 15))
         return launch_scatter_rows(b, c, n, p, grad_out, idx, grad_points, (hipStream_t)stream, "group_points_grad");
     return launch_scatter_rows_csr(b, c, n, p, grad_out, idx, grad_points, workspace, workspace_bytes, (hipStream_t)stream,
                                    "group_points_grad", 0);
@@ -768,7 +621,7 @@ extern "C" int epnet_group_concat_grad_ws(int b, int c, int n, int npoints, int 
     if (b == 0 || c == 0 || p == 0) return EPNET_OK;
     const int ch0 = use_xyz ? 3 : 0;
     const size_t gstride = (size_t)(ch0 + c) * (size_t)p;
-    if (scatter_ws_bytes(b, n, p) == 0)
+    if (scatter_ws_bytes(b, n, p) == 0 || ((uintptr_t)grad_out & 15))
         return launch_scatter_rows(b, c, n, p, grad_out + (size_t)ch0 * p, idx, grad_features, (hipStream_t)stream,
                                    "group_concat_grad", gstride);
     return launch_scatter_rows_csr(b, c, n, p, grad_out + (size_t)ch0 * p, idx, grad_features, workspace, workspace_bytes,

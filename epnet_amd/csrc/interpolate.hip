@@ -21,6 +21,7 @@
 #include "common.h"
 #include "dpp.h"
 #include "spatial.h"
+#include "runsum.h"
 
 namespace epnet {
 
@@ -490,113 +491,6 @@ __global__ __launch_bounds__(kTiThreads) void three_interpolate_grad_lds_kernel(
     for (int e = threadIdx.x; e < nr * m; e += kTiThreads) gp[e] += acc[e];
 }
 
-// atomic-free gradient (see scatter_rows_csr_kernel in group.hip): the 3n (unknown, slot) pairs are grouped by
-// their known point; a workgroup stages ROWS rows of grad_out in LDS and every known point j sums
-// w * grad_out over its own list.
-// The unknowns are cut into `parts` runs of part_len: a workgroup stages ROWS rows of ONE run at a time (so 8 rows fit
-// LDS even at n = 16384), the inverse index is keyed by (run, known point), and a thread carries its partial sums
-// across the runs -- the index is read once per 8 rows instead of once per 2.
-constexpr int kTigThreads = 1024;
-constexpr int kTigMaxTargets = 4;  // known points per thread: m <= 4096 per pass
-template <int ROWS>
-__global__ __launch_bounds__(kTigThreads) void three_interpolate_grad_csr_kernel(int c, int n, int m, int parts, int part_len,
-                                                                               const float *__restrict__ grad_out,
-                                                                               const float *__restrict__ weight,
-                                                                               const int *__restrict__ offsets,
-                                                                               const int *__restrict__ perm,
-                                                                               float *__restrict__ grad_points) {
-    extern __shared__ float s_go[];  // ROWS * part_len floats
-    __shared__ int s_long[kLongQueue];
-    __shared__ int s_nlong;
-    const int bs = blockIdx.y;
-    const int c0 = blockIdx.x * ROWS;
-    const int nr = min(ROWS, c - c0);
-    const float *go = grad_out + ((size_t)bs * c + c0) * n;
-    offsets += (size_t)bs * ((size_t)parts * m + 1);
-    perm += (size_t)bs * n * 3;
-    weight += (size_t)bs * n * 3;
-    float *gp = grad_points + ((size_t)bs * c + c0) * m;
-    for (int j0 = 0; j0 < m; j0 += kTigThreads * kTigMaxTargets) {  // one pass for m <= 4096
-        float acc[kTigMaxTargets][ROWS];
-#pragma unroll
-        for (int u = 0; u < kTigMaxTargets; ++u)
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) acc[u][r] = 0.f;
-        for (int part = 0; part < parts; ++part) {
-            const int i0 = part * part_len, len = min(part_len, n - i0);
-            __syncthreads();  // the previous run is no longer being read
-            for (int r = 0; r < nr; ++r) {
-                const float *src = go + (size_t)r * n + i0;
-                float *dst = s_go + r * part_len;
-                if ((len & 3) == 0 && ((uintptr_t)src & 15) == 0) {
-                    for (int e = threadIdx.x; e < len / 4; e += kTigThreads)
-                        reinterpret_cast<float4 *>(dst)[e] = reinterpret_cast<const float4 *>(src)[e];
-                } else {
-                    for (int e = threadIdx.x; e < len; e += kTigThreads) dst[e] = src[e];
-                }
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) s_nlong = 0;
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < kTigMaxTargets; ++u) {
-                const int j = j0 + u * kTigThreads + threadIdx.x;
-                if (j >= m) continue;
-                const int beg = offsets[part * m + j], end = offsets[part * m + j + 1];
-                if (end - beg > kLongList) {  // summed by a whole wave below
-                    const int slot = atomicAdd(&s_nlong, 1);
-                    if (slot < kLongQueue) {
-                        s_long[slot] = j;
-                        continue;
-                    }
-                }
-                for (int t = beg; t < end; ++t) {
-                    const int q = perm[t];  // = unknown * 3 + slot
-                    const int i = q / 3 - i0;
-                    const float w = weight[q];
-#pragma unroll
-                    for (int r = 0; r < ROWS; ++r)
-                        if (r < nr) acc[u][r] += s_go[r * part_len + i] * w;
-                }
-            }
-            __syncthreads();
-            // the FPS-subset known points near the sensor are nearest to hundreds of unknowns: whole waves take them
-            const int nlong = min(s_nlong, kLongQueue);
-            const int lane = threadIdx.x & 63;
-            for (int li = threadIdx.x >> 6; li < nlong; li += kTigThreads / 64) {
-                const int j = s_long[li];
-                const int beg = offsets[part * m + j], end = offsets[part * m + j + 1];
-                float part_acc[ROWS];
-#pragma unroll
-                for (int r = 0; r < ROWS; ++r) part_acc[r] = 0.f;
-                for (int t = beg + lane; t < end; t += 64) {
-                    const int q = perm[t];
-                    const int i = q / 3 - i0;
-                    const float w = weight[q];
-#pragma unroll
-                    for (int r = 0; r < ROWS; ++r)
-                        if (r < nr) part_acc[r] += s_go[r * part_len + i] * w;
-                }
-#pragma unroll
-                for (int r = 0; r < ROWS; ++r) {
-                    const float sum = wave_sum_f32(part_acc[r]);
-                    if (r < nr && lane == 0) gp[(size_t)r * m + j] += sum;
-                }
-            }
-        }
-        __threadfence_block();
-        __syncthreads();  // the waves' direct additions above land before the owners add their own sums
-#pragma unroll
-        for (int u = 0; u < kTigMaxTargets; ++u) {
-            const int j = j0 + u * kTigThreads + threadIdx.x;
-            if (j >= m) continue;
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r)
-                if (r < nr) gp[(size_t)r * m + j] += acc[u][r];
-        }
-    }
-}
-
 __global__ __launch_bounds__(kTiThreads) void three_interpolate_grad_atomic_kernel(int c, int n, int m,
                                                                                    const float *__restrict__ grad_out,
                                                                                    const int *__restrict__ idx,
@@ -713,53 +607,24 @@ extern "C" int epnet_three_nn_ws(int b, int n, int m, const float *unknown, cons
 
 // runs the unknowns are cut into: the fewest (power of two) that let 8 rows of one run fit LDS, as long as the
 // inverse index keeps at most 16384 keys
-static int tig_parts(int b, int c, int n, int m) {
-    // runs serialise a workgroup's staging; they pay once there are enough workgroups of 8 rows to fill the chip
-    // (B=16, C=256, n=16384 on FP-module indices: 2.86 -> 1.45 ms; B=1: 0.40 -> 0.75 ms)
-    if ((long long)b * div_up(c, 8) < 512) return 1;
-    int parts = 1;
-    while (parts < 16 && (long long)div_up(n, parts) * 4 * 8 > 128 * 1024 && (long long)parts * 2 * m <= 16384) parts *= 2;
-    return parts;
-}
-
+// atomic-free gradient (runsum.h): the 3n (unknown, neighbour) pairs grouped by their known point once, then equal shares
+// of the sorted pairs summed per thread (w * grad_out) out of LDS-staged grad_out rows
 extern "C" size_t epnet_three_interpolate_grad_workspace_bytes(int b, int n, int m) {
-    if (b <= 0 || n <= 0 || m <= 0 || m > 16384 || (long long)n * 4 > 128 * 1024) return 0;
-    // sized for the largest partition the launcher may pick (it depends on the channel count as well)
-    int parts = 1;
-    while (parts < 16 && (long long)parts * 2 * m <= 16384) parts *= 2;
-    return (size_t)b * ((size_t)parts * m + 1 + (size_t)n * 3) * sizeof(int);
+    if (b <= 0 || !runsum::usable(m, (long long)n * 3, n)) return 0;
+    return runsum::workspace_bytes(b, (long long)n * 3, true);
 }
 
 extern "C" int epnet_three_interpolate_grad_ws(int b, int c, int n, int m, const float *grad_out, const int *idx,
                                                const float *weight, float *grad_points, void *workspace,
                                                size_t workspace_bytes, epnet_stream_t stream) {
     const size_t need = epnet_three_interpolate_grad_workspace_bytes(b, n, m);
-    if (need == 0) return epnet_three_interpolate_grad(b, c, n, m, grad_out, idx, weight, grad_points, stream);
+    if (need == 0 || ((uintptr_t)grad_out & 15))
+        return epnet_three_interpolate_grad(b, c, n, m, grad_out, idx, weight, grad_points, stream);
     EPNET_REQUIRE(b >= 0 && c >= 0);
     if (b == 0 || c == 0) return EPNET_OK;
     EPNET_REQUIRE(grad_out && idx && weight && grad_points && workspace);
-    if (workspace_bytes < need) return EPNET_ENOMEM;
-    if (b > 65535) return EPNET_ELIMIT;
-    hipStream_t s = (hipStream_t)stream;
-    const int parts = tig_parts(b, c, n, m);
-    const int part_len = div_up(div_up(n, parts), 4) * 4;  // 16-byte rows in LDS
-    int *offsets = (int *)workspace;
-    int *perm = offsets + (size_t)b * ((size_t)parts * m + 1);
-    int rc = csr_build_launch(b, parts * m, n * 3, idx, offsets, perm, s, parts > 1 ? 3 * part_len : 0, m);
-    if (rc) return rc;
-    const int fit = (128 * 1024) / (part_len * 4);
-    const int rows = fit >= 8 ? 8 : fit >= 4 ? 4 : fit >= 2 ? 2 : 1;
-    const size_t lds = (size_t)rows * part_len * 4;
-    dim3 grid(div_up(c, rows), b);
-#define EPNET_TIG(R_) hipLaunchKernelGGL(three_interpolate_grad_csr_kernel<R_>, grid, dim3(kTigThreads), lds, s, c, n, m, parts, part_len, grad_out, weight, offsets, perm, grad_points)
-    switch (rows) {
-        case 8: EPNET_TIG(8); break;
-        case 4: EPNET_TIG(4); break;
-        case 2: EPNET_TIG(2); break;
-        default: EPNET_TIG(1); break;
-    }
-#undef EPNET_TIG
-    return check_launch("three_interpolate_grad");
+    return runsum::launch<true>(b, c, m, n * 3, 3, n, grad_out, (size_t)c * n, idx, weight, grad_points, workspace, workspace_bytes,
+                                (hipStream_t)stream, "three_interpolate_grad");
 }
 
 // three_nn over scene indices built beforehand (epnet_scene_index_build): of the known set, and optionally of the

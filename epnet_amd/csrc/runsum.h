@@ -1,0 +1,333 @@
+// runsum.h -- scatter-add without atomics for the three gradient ops (gather / group_points / three_interpolate grads;
+// reference: sampling_gpu.cu:46-63, group_points_gpu.cu:8-25, interpolate_gpu.cu:120-142, all atomicAdd scatters).
+//
+// grad_points[c][j] = sum over the entries t with key(t) = j of  grad_out[c][pos(t)] (* weight[t]).
+//
+// Two kernels, both over caller scratch:
+//   pack_kernel     groups the entries of a scene by their target once (counting sort in LDS, `parts` workgroups per
+//                   scene, each owning a range of targets) into 32-bit words  end << 31 | key << 16 | pos, `end` marking
+//                   the last entry of a target's run; the array is padded to a multiple of 4096 with entries of a dump
+//                   target and stored blocked-transposed, so that thread q of the sum kernel owns the sorted slots
+//                   [q * ept, (q + 1) * ept) and still reads them with coalesced 16-byte loads.
+//   scatter_kernel  one 1024-thread workgroup walks a sequence of channel-row groups of one scene. Per group: the R rows of
+//                   grad_out are copied into LDS (16-byte loads, each element read from HBM once; the NEXT group's rows are
+//                   already on their way into registers while this group is summed), every thread sums its ept entries
+//                   in sorted order -- closed runs go to the LDS copy of the output row with plain stores, a run that
+//                   crosses thread boundaries is finished by the thread it starts in (partial sums handed over through
+//                   LDS) -- and the output rows are added to grad_points with coalesced 16-byte accesses.
+// Every thread does the same amount of work whatever the list lengths are (ball-query padding repeats an index up to
+// nsample times, FPS-subset points near the sensor are nearest to hundreds of unknowns), no list is walked through a
+// chain of dependent loads, and nothing is atomic. The order of the terms inside a run is whatever the counting sort
+// produced (the reference's atomicAdd order is unspecified as well).
+#pragma once
+#include "common.h"
+#include "spatial.h"
+
+namespace epnet {
+namespace runsum {
+
+constexpr int kThreads = 1024;
+constexpr int kChunk = kThreads * 4;      // the entry array is padded to whole 16-byte loads of the workgroup
+constexpr int kMaxEntries = 65536;        // pos field: 16 bits
+constexpr int kMaxRowFloats = 32768;      // 128 KB of LDS for the staged rows
+constexpr int kMaxTargets = 16384;        // key field: 15 bits, one value kept for the dump target
+constexpr int kLdsLimit = 158 * 1024;
+
+__host__ __device__ inline int padded_entries(int p) { return (p + kChunk - 1) / kChunk * kChunk; }
+
+// memory index of sorted slot s (thread s / ept holds it as element s % ept): 16-byte groups interleaved over the threads
+__host__ __device__ inline int slot_to_mem(int s, int ept) {
+    const int q = s / ept, i = s - q * ept;
+    return (((i >> 2) * kThreads) + q) * 4 + (i & 3);
+}
+
+inline bool usable(int n, long long entries, long long row_floats) {
+    return n >= 1 && n <= kMaxTargets && entries >= 1 && entries <= kMaxEntries && row_floats >= 4 && row_floats <= kMaxRowFloats &&
+           row_floats % 4 == 0;
+}
+
+inline size_t lds_bytes(int rows, int n, int row_floats) {
+    const int n_pad = (n + 1 + 3) / 4 * 4;
+    return ((size_t)rows * row_floats + (size_t)rows * n_pad + (size_t)rows * kThreads) * sizeof(float);
+}
+
+// rows per pass: as many as fit (the entry words are read once per pass), but not so many that the chip runs short of
+// workgroups
+inline int pick_rows(int b, int c, int n, int row_floats) {
+    int rows = 8;
+    while (rows > 1 && ((long long)rows * row_floats > kMaxRowFloats || lds_bytes(rows, n, row_floats) > (size_t)kLdsLimit)) rows >>= 1;
+    while (rows > 1 && (long long)b * div_up(c, rows) < 256) rows >>= 1;
+    return rows;
+}
+
+inline size_t workspace_bytes(int b, long long entries, bool weighted) {
+    return (size_t)b * (size_t)padded_entries((int)entries) * (weighted ? 8 : 4);
+}
+
+// ---- the inverse index -------------------------------------------------------------------------------------------
+// grid (parts, b). idx: (b, p) targets, clamped into [0, n) (an index outside is undefined behaviour in the reference;
+// here it cannot leave the scene). pos of entry t = t / div (div = 3: the three neighbours of an unknown point).
+template <bool W>
+__global__ __launch_bounds__(kThreads) void pack_kernel(int n, int p, int div, const int *__restrict__ idx,
+                                                        const float *__restrict__ weight, unsigned *__restrict__ ent,
+                                                        float *__restrict__ wsorted) {
+    extern __shared__ int s_bins[];  // counts (nb), then run starts (nb + 1)
+    __shared__ int s_part[kThreads / 64];
+    __shared__ int s_below[kThreads / 64];
+    const int q = threadIdx.x, lane = q & 63, wave = q >> 6;
+    const int parts = gridDim.x, part = blockIdx.x, bs = blockIdx.y;
+    const int P = padded_entries(p), ept = P / kThreads;
+    idx += (size_t)bs * p;
+    ent += (size_t)bs * P;
+    if (W) {
+        weight += (size_t)bs * p;
+        wsorted += (size_t)bs * P;
+    }
+    const int nb = (n + parts - 1) / parts;
+    const int j0 = part * nb, j1 = min(n, j0 + nb);
+    int *s_cnt = s_bins, *s_start = s_bins + nb;
+    for (int i = q; i < nb; i += kThreads) s_cnt[i] = 0;
+    __syncthreads();
+    int below = 0;
+    for (int t = q; t < p; t += kThreads) {
+        const int j = min(max(idx[t], 0), n - 1);
+        if (j < j0) ++below;
+        else if (j < j1) atomicAdd(&s_cnt[j - j0], 1);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) below += __shfl_xor(below, off, 64);
+    if (lane == 0) s_below[wave] = below;
+    __syncthreads();
+    const int per = (nb + kThreads - 1) / kThreads;
+    int sum = 0;
+    for (int i = 0; i < per; ++i) {
+        const int k = q * per + i;
+        if (k < nb) sum += s_cnt[k];
+    }
+    const int incl = wave_inclusive_scan(sum);
+    if (lane == 63) s_part[wave] = incl;
+    __syncthreads();
+    int base = incl - sum;
+    for (int w = 0; w < wave; ++w) base += s_part[w];
+    int before = 0;
+    for (int w = 0; w < kThreads / 64; ++w) before += s_below[w];
+    for (int i = 0; i < per; ++i) {
+        const int k = q * per + i;
+        if (k < nb) {
+            s_start[k] = before + base;
+            base += s_cnt[k];
+        }
+    }
+    if (q == 0) {  // end of the last run of the range
+        int total = before;
+        for (int w = 0; w < kThreads / 64; ++w) total += s_part[w];
+        s_start[nb] = total;
+    }
+    __syncthreads();
+    for (int t = q; t < p; t += kThreads) {
+        const int j = min(max(idx[t], 0), n - 1);
+        if (j < j0 || j >= j1) continue;
+        const int old = atomicSub(&s_cnt[j - j0], 1);  // the run is filled from its end: old = entries still to place
+        const int slot = s_start[j - j0] + old - 1;
+        const unsigned end = (slot + 1 == s_start[j - j0 + 1]) ? 0x80000000u : 0u;
+        const int at = slot_to_mem(slot, ept);
+        ent[at] = end | ((unsigned)j << 16) | (unsigned)(t / div);
+        if (W) wsorted[at] = weight[t];
+    }
+    if (part == parts - 1)  // padding: one run of a dump target (key n) that reads position 0 with weight 0
+        for (int s = p + q; s < P; s += kThreads) {
+            const int at = slot_to_mem(s, ept);
+            ent[at] = (s == P - 1 ? 0x80000000u : 0u) | ((unsigned)n << 16);
+            if (W) wsorted[at] = 0.f;
+        }
+}
+
+// ---- the sums ----------------------------------------------------------------------------------------------------
+// grid (workgroups per scene, b); workgroup x takes the row groups [x * per_wg, (x + 1) * per_wg) of its scene.
+// grad_out rows of a scene: grad_out + bs * gstride + row * row_floats; grad_points rows: ((bs * c) + row) * n.
+template <int R, bool W>
+__global__ __launch_bounds__(kThreads) void scatter_kernel(int c, int n, int row_floats, int P, int per_wg, int vec_out, size_t gstride,
+                                                           const float *__restrict__ grad_out,
+                                                           const unsigned *__restrict__ ent,
+                                                           const float *__restrict__ wsorted,
+                                                           float *__restrict__ grad_points) {
+    extern __shared__ float s_mem[];
+    __shared__ unsigned char s_whole[kThreads];
+    const int q = threadIdx.x, bs = blockIdx.y;
+    const int n_pad = (n + 1 + 3) / 4 * 4;
+    float *s_row = s_mem;                           // R rows of grad_out
+    float *s_out = s_row + (size_t)R * row_floats;  // R output rows (+ the dump slot n)
+    float *s_first = s_out + (size_t)R * n_pad;     // partial sum of the run a thread's range starts inside of
+    const int ept = P / kThreads, nq = ept >> 2;
+    const uint4 *ent4 = reinterpret_cast<const uint4 *>(ent + (size_t)bs * P);
+    const float4 *w4p = W ? reinterpret_cast<const float4 *>(wsorted + (size_t)bs * P) : nullptr;
+    const int groups = (c + R - 1) / R;
+    const int g_beg = blockIdx.x * per_wg, g_end = min(groups, g_beg + per_wg);
+    if (g_beg >= g_end) return;
+
+    // what a thread needs to know about its slice of the sorted entries, the same for every row
+    bool open_start = false;
+    if (q > 0) open_start = !(ent[(size_t)bs * P + slot_to_mem(q * ept - 1, ept)] >> 31);
+    bool any_end = false;
+    unsigned last = 0;
+    for (int g = 0; g < nq; ++g) {
+        const uint4 e = ent4[g * kThreads + q];
+        any_end = any_end || ((e.x | e.y | e.z | e.w) >> 31);
+        last = e.w;
+    }
+    const bool open_end = !(last >> 31);
+    const bool whole = open_start && !any_end;  // one link of a run that began before and ends after this thread's range
+    const bool head = open_end && !whole;       // the run this thread's range ends inside of begins here: finish it
+    const int last_key = (int)((last >> 16) & 0x7FFFu);
+    s_whole[q] = whole ? 1 : 0;
+    for (int i = q; i < R * n_pad; i += kThreads) s_out[i] = 0.f;
+
+    const float *go = grad_out + (size_t)bs * gstride;
+    float *gp = grad_points + (size_t)bs * c * n;
+    const int row4 = row_floats >> 2;
+    constexpr int kPre = 8;  // R * row_floats <= 32768 floats = 8 x 16 bytes per thread
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 pre[kPre];
+    auto fetch = [&](int g) {
+        const int nr = min(R, c - g * R);
+        const f4 *src = reinterpret_cast<const f4 *>(go + (size_t)g * R * row_floats);
+        const int total4 = nr * row4;
+#pragma unroll
+        for (int k = 0; k < kPre; ++k) {
+            const int e = k * kThreads + q;
+            if (e < total4) pre[k] = src[e];
+        }
+    };
+    fetch(g_beg);
+    for (int g = g_beg; g < g_end; ++g) {
+        const int c0 = g * R, nr = min(R, c - c0);
+        {
+            const int total4 = nr * row4;
+            f4 *dst = reinterpret_cast<f4 *>(s_row);
+#pragma unroll
+            for (int k = 0; k < kPre; ++k) {
+                const int e = k * kThreads + q;
+                if (e < total4) dst[e] = pre[k];
+            }
+        }
+        if (g + 1 < g_end) fetch(g + 1);  // in flight while this group is summed
+        __syncthreads();
+        float acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = 0.f;
+        bool first_open = open_start;
+        for (int gi = 0; gi < nq; ++gi) {
+            const uint4 e4 = ent4[gi * kThreads + q];
+            float4 w4 = {1.f, 1.f, 1.f, 1.f};
+            if (W) w4 = w4p[gi * kThreads + q];
+            const unsigned es[4] = {e4.x, e4.y, e4.z, e4.w};
+            const float ws[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned e = es[k];
+                const int pos = (int)(e & 0xFFFFu);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float v = s_row[r * row_floats + pos];
+                    acc[r] += W ? v * ws[k] : v;
+                }
+                if (e >> 31) {
+                    const int key = (int)((e >> 16) & 0x7FFFu);
+                    if (first_open) {
+#pragma unroll
+                        for (int r = 0; r < R; ++r) s_first[r * kThreads + q] = acc[r];
+                        first_open = false;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < R; ++r) s_out[r * n_pad + key] = acc[r];
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; ++r) acc[r] = 0.f;
+                }
+            }
+        }
+        if (whole) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) s_first[r * kThreads + q] = acc[r];
+        }
+        __syncthreads();
+        if (head) {  // collect the links of the run up to the thread it ends in
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float total = acc[r];
+                int k = q + 1;
+                while (k < kThreads) {
+                    total += s_first[r * kThreads + k];
+                    if (!s_whole[k]) break;
+                    ++k;
+                }
+                s_out[r * n_pad + last_key] = total;
+            }
+        }
+        __syncthreads();
+        // grad_points += the output rows; the LDS copies go back to zero for the next group
+        if (vec_out) {
+            const int n4 = n >> 2;
+            for (int i = q; i < nr * n4; i += kThreads) {
+                const int r = i / n4, j4 = i - r * n4;
+                float4 *so = reinterpret_cast<float4 *>(s_out + r * n_pad) + j4;
+                float4 *dst = reinterpret_cast<float4 *>(gp + (size_t)(c0 + r) * n) + j4;
+                const float4 a = *so, o = *dst;
+                *dst = make_float4(o.x + a.x, o.y + a.y, o.z + a.z, o.w + a.w);
+                *so = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+            for (int i = q; i < nr * n; i += kThreads) {
+                const int r = i / n, j = i - r * n;
+                gp[(size_t)(c0 + r) * n + j] += s_out[r * n_pad + j];
+                s_out[r * n_pad + j] = 0.f;
+            }
+        }
+        // (the next group's rows overwrite s_row only after every thread has passed the barrier before the head step, and
+        // its sums start only after the barrier that follows the copy: the zeroing above is complete by then)
+    }
+}
+
+template <bool W>
+inline int launch(int b, int c, int n, int entries, int div, int row_floats, const float *grad_out, size_t gstride,
+                  const int *idx, const float *weight, float *grad_points, void *workspace, size_t workspace_bytes_given,
+                  hipStream_t s, const char *what) {
+    if (workspace_bytes_given < workspace_bytes(b, entries, W)) return EPNET_ENOMEM;
+    if (b > 65535) return EPNET_ELIMIT;
+    if (((uintptr_t)grad_out | (uintptr_t)(gstride * sizeof(float))) & 15) return EPNET_EINVAL;  // callers check alignment first
+    const int P = padded_entries(entries);
+    unsigned *ent = (unsigned *)workspace;
+    float *wsorted = W ? (float *)(ent + (size_t)b * P) : nullptr;
+    // parts: enough workgroups to spread the counting sort over the chip, each with at least a few hundred targets
+    int parts = b >= 128 ? 1 : b >= 32 ? 4 : b >= 8 ? 8 : 16;
+    while (parts > 1 && n / parts < 256) parts >>= 1;
+    const int nb = div_up(n, parts);
+    hipLaunchKernelGGL((pack_kernel<W>), dim3(parts, b), dim3(kThreads), (size_t)(2 * nb + 1) * sizeof(int), s, n, entries, div, idx,
+                       weight, ent, wsorted);
+    int rc = check_launch("inverse index");
+    if (rc) return rc;
+    const int rows = pick_rows(b, c, n, row_floats);
+    const int groups = div_up(c, rows);
+    // about two workgroups per CU over the whole launch (one resident at a time when a row fills the LDS), whole passes
+    const size_t lds = lds_bytes(rows, n, row_floats);
+    int wgs = (lds > 80 * 1024 ? 256 : 512) / b;
+    if (wgs < 1) wgs = 1;
+    if (wgs > groups) wgs = groups;
+    const int per_wg = div_up(groups, wgs);
+    wgs = div_up(groups, per_wg);
+    const int vec_out = ((n & 3) == 0 && ((uintptr_t)grad_points & 15) == 0) ? 1 : 0;
+    dim3 grid(wgs, b);
+#define EPNET_RUNSUM(R_) \
+    hipLaunchKernelGGL((scatter_kernel<R_, W>), grid, dim3(kThreads), lds, s, c, n, row_floats, P, per_wg, vec_out, gstride, grad_out, ent, wsorted, grad_points)
+    switch (rows) {
+        case 8: EPNET_RUNSUM(8); break;
+        case 4: EPNET_RUNSUM(4); break;
+        case 2: EPNET_RUNSUM(2); break;
+        default: EPNET_RUNSUM(1); break;
+    }
+#undef EPNET_RUNSUM
+    return check_launch(what);
+}
+
+}  // namespace runsum
+}  // namespace epnet

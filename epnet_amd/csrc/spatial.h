@@ -193,11 +193,6 @@ __device__ __forceinline__ void cell_sort_lds(const float *__restrict__ xyz, int
     __syncthreads();
 }
 
-// defined in group.hip: per scene, offsets (n+1 ints) and perm (p ints) = the positions 0..p-1 grouped by target idx[.] < n <= 16384
-// key of position t: idx[t] + (key_div ? (t / key_div) * key_mul : 0), n = number of keys
-int csr_build_launch(int b, int n, int p, const int *idx, int *offsets, int *perm, hipStream_t s, int key_div = 0,
-                     int key_mul = 0);
-
 // ---- scene index: caller scratch shared by FPS, ball query and three_nn of one level ---------------------
 // per scene: the points counting-sorted by cell as float4 (x, y, z, original index; padding = 3e38 / -1),
 // padded to np = a power of two >= 2048, followed (after all scenes) by one box (6 floats) per 64 sorted points

@@ -414,6 +414,82 @@ def test_group_points_grad(oracle, b, c, n, m, ns):
     np.testing.assert_allclose(host(grad), oracle.group_points_grad(go, idx, n), rtol=1e-5, atol=1e-5)
 
 
+def _skewed_indices(rng, b, n, count, mode):
+    """neighbour lists as uneven as real ones get (and worse)"""
+    if mode == "uniform":
+        return rng.integers(0, n, size=(b, count))
+    if mode == "one":            # every entry to ONE target: a single run across all 1024 threads of the sum kernel
+        return np.full((b, count), n // 3)
+    if mode == "few":            # a handful of targets share everything
+        return rng.choice(np.array([0, 1, n // 2, n - 1]), size=(b, count))
+    if mode == "zipf":           # a few targets with thousands of entries, a long tail with one or none
+        z = rng.zipf(1.3, size=(b, count))
+        return np.minimum(z - 1, n - 1)
+    if mode == "blocks":         # ball-query padding: one index repeated nsample times in a row
+        return np.repeat(rng.integers(0, n, size=(b, (count + 31) // 32)), 32, axis=1)[:, :count]
+    raise ValueError(mode)
+
+
+@pytest.mark.parametrize("b,c,n,m,ns,mode", [
+    (16, 96, 4096, 1024, 32, "blocks"),    # the level-2 shape: one 128 KB row per pass
+    (3, 10, 4096, 1024, 32, "zipf"),
+    (2, 7, 4096, 1024, 32, "one"),
+    (2, 5, 4096, 1024, 32, "few"),
+    (2, 96, 4096, 1024, 16, "uniform"),    # two rows per pass
+    (5, 33, 1024, 256, 16, "zipf"),        # four / eight rows per pass, channel count not a multiple of it
+    (130, 19, 512, 128, 64, "blocks"),     # RCNN shape, many scenes
+    (2, 9, 333, 128, 8, "uniform"),        # target count not a multiple of 4: scalar write-back
+    (2, 4, 1000, 1024, 4, "one"),          # exactly one chunk of entries, no padding
+    (1, 3, 16384, 1025, 4, "zipf"),        # 4100 entries: 4092 padding entries of the dump target
+    (2, 6, 50, 16, 4, "few"),              # 64 entries for 1024 threads: almost everything is padding
+])
+def test_group_points_grad_uneven_lists(oracle, b, c, n, m, ns, mode):
+    """the run-sum gradient (csrc/runsum.h) on neighbour lists of every shape: equal shares of the sorted entries per
+    thread, runs handed across thread boundaries, the padding run, rows per pass from 1 to 8; accumulation INTO the buffer"""
+    from epnet_amd import pointnet2_cuda as ext
+    rng = np.random.default_rng(b * 131 + c)
+    go = rng.standard_normal((b, c, m, ns)).astype(np.float32)
+    idx = _skewed_indices(rng, b, n, m * ns, mode).reshape(b, m, ns).astype(np.int32)
+    start = rng.standard_normal((b, c, n)).astype(np.float32)
+    grad = dev(start)
+    ext.group_points_grad_wrapper(b, c, n, m, ns, dev(go), dev(idx), grad)
+    # float64 yardstick with a per-element bound from the list's sum of magnitudes: the order of a list's terms is free
+    # (atomicAdd in the reference), so a list of 32768 terms may differ from the oracle's sequential fp32 sum by more than 1e-5
+    want = np.zeros((b, c, n))
+    mag = np.zeros((b, c, n))
+    flat = idx.reshape(b, -1).astype(np.int64)
+    for s_ in range(b):
+        np.add.at(want[s_].T, flat[s_], go[s_].reshape(c, -1).T.astype(np.float64))
+        np.add.at(mag[s_].T, flat[s_], np.abs(go[s_].reshape(c, -1).T).astype(np.float64))
+    err = np.abs(host(grad).astype(np.float64) - (start + want))
+    assert (err <= 1e-7 * mag + 1e-5 * np.maximum(1.0, np.abs(start + want))).all(), float(err.max())
+    np.testing.assert_allclose(oracle.group_points_grad(go, idx, n), want, rtol=1e-3, atol=1e-2)   # the oracle agrees with the yardstick
+
+
+@pytest.mark.parametrize("b,c,n,m,mode", [(16, 32, 16384, 4096, "zipf"), (2, 9, 16384, 4096, "one"), (3, 17, 4096, 1024, "uniform"),
+                                          (2, 40, 1024, 256, "few"), (4, 6, 256, 64, "zipf"), (2, 3, 21844, 100, "uniform")])
+def test_three_interpolate_grad_uneven_lists(oracle, b, c, n, m, mode):
+    from epnet_amd import pointnet2_cuda as ext
+    rng = np.random.default_rng(b * 17 + c)
+    go = rng.standard_normal((b, c, n)).astype(np.float32)
+    idx = _skewed_indices(rng, b, m, n * 3, mode).reshape(b, n, 3).astype(np.int32)
+    w = rng.random((b, n, 3)).astype(np.float32)
+    w /= w.sum(-1, keepdims=True)
+    start = rng.standard_normal((b, c, m)).astype(np.float32)
+    grad = dev(start)
+    ext.three_interpolate_grad_wrapper(b, c, n, m, dev(go), dev(idx), dev(w), grad)
+    terms = (go[:, :, :, None].astype(np.float64) * w[:, None, :, :].astype(np.float32).astype(np.float64)).reshape(b, c, n * 3)
+    flat = idx.reshape(b, -1).astype(np.int64)
+    want = np.zeros((b, c, m))
+    mag = np.zeros((b, c, m))
+    for s_ in range(b):
+        np.add.at(want[s_].T, flat[s_], terms[s_].T)
+        np.add.at(mag[s_].T, flat[s_], np.abs(terms[s_]).T)
+    err = np.abs(host(grad).astype(np.float64) - (start + want))
+    assert (err <= 2e-7 * mag + 1e-5 * np.maximum(1.0, np.abs(start + want))).all(), float(err.max())
+    np.testing.assert_allclose(oracle.three_interpolate_grad(go, idx, w, m), want, rtol=1e-3, atol=1e-2)
+
+
 def test_gather_points_grad_and_accumulation(oracle):
     from epnet_amd import pointnet2_cuda as ext
     rng = np.random.default_rng(11)

@@ -110,7 +110,9 @@ def test_forward_normalises_xy_in_place_like_the_reference(monkeypatch, oracle):
 @pytest.mark.parametrize("sampler", ["hip", "stock"])
 def test_reduced_model_reproduces_the_reference_on_gpu(hiplib, sampler):
     model, fx = load_small(sampler, "cuda:0")
-    run_small(model, fx, "cuda:0", rtol=5e-4, atol=5e-5)
+    # the fixture was computed on the CPU: the dense layers (MIOpen / rocBLAS against the CPU's kernels) sum in other orders
+    # and training-mode batch norm over 8..1024 columns amplifies that; the geometry ops themselves are exact
+    run_small(model, fx, "cuda:0", rtol=2e-3, atol=3e-4)
 
 
 @pytest.mark.gpu
