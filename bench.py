@@ -39,9 +39,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("EPNET_BENCH_BATCH", "256")),
-                    help="scenes per GPU per step")
-    ap.add_argument("--points", type=int, default=16384)
+    ap.add_argument("--batch", type=int, default=None,
+                    help="scenes per GPU per step (default 256 for config 2, 64 for config 5; EPNET_BENCH_BATCH overrides)")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 5],
+                    help="BASELINE.json config: 2 = 16384-point scenes through the 4-level stack (the metric's configuration), "
+                         "5 = dense 65536-point scenes, one level: FPS 16384, ball query r 0.5 / nsample 64, grouping C = 3 and 64")
+    ap.add_argument("--points", type=int, default=None, help="points per scene (default: the config's)")
     ap.add_argument("--kind", default="kitti", choices=["kitti", "ubox", "dup"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-overlap", action="store_true",
@@ -57,27 +60,42 @@ def parse():
                          "flipped cloud, transpose back: pointnet2_modules.py:30-45) instead of epnet_sample_centres (FPS + row gather "
                          "of the centres, same idx / new_xyz): 6 instead of 3 launches per level on the sampling chain")
     ap.add_argument("--with-fp", action="store_true", help="also run the 4 three_nn + 4 three_interpolate FP ops")
-    ap.add_argument("--cpu-scenes", type=int, default=int(os.environ.get("EPNET_BENCH_CPU_SCENES", "16")),
-                    help="scenes in the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--cpu-scenes", type=int, default=None,
+                    help="scenes in the cpu_baseline sample (0 = skip; default 16 for config 2, 2 for config 5)")
     ap.add_argument("--sweep", default="", help="comma list of extra batch sizes to time (reported under 'sweep')")
+    ap.add_argument("--extras", default="b1,with_fp,config5",
+                    help="further measurements reported as sub-objects of the default N = 1 line (comma list of b1, with_fp, config5; "
+                         "empty = none)")
     ap.add_argument("--verify-scenes", type=int, default=1,
                     help="scenes of the timed buffers rank 0 checks against the CPU oracle after the timed loop (0 = skip; "
                          "the line then carries verified: null)")
     ap.add_argument("--launch-check", action="store_true",
                     help="rehearse the N-rank launch only: the ranks rendezvous (backend EPNET_BENCH_BACKEND, default nccl), "
                          "count themselves with an all-reduce and rank 0 prints n_gpus / ranks_seen; no kernels of the path")
-    return ap.parse_args()
+    args = ap.parse_args()
+    from epnet_amd import sa_stack
+    args.cfg = sa_stack.CONFIGS[args.config]
+    if args.points is None:
+        args.points = args.cfg["n"]
+    if args.batch is None:
+        args.batch = int(os.environ.get("EPNET_BENCH_BATCH", "256" if args.config == 2 else "64"))
+    if args.cpu_scenes is None:
+        args.cpu_scenes = int(os.environ.get("EPNET_BENCH_CPU_SCENES", "16" if args.config == 2 else "2"))
+    if args.with_fp and args.config != 2:
+        ap.error("--with-fp belongs to config 2 (the FP modules of the RPN pyramid)")
+    return args
 
 
 _CPU_JOBS = {}  # inputs of the CPU baselines, prepared in the parent and inherited by forked workers
 
 
-def _cpu_prepare(kind, n_points, seeds):
+def _cpu_prepare(kind, n_points, seeds, cfg):
     import numpy as np
-    from epnet_amd import sa_stack, synth
+    from epnet_amd import synth
     rng = np.random.default_rng(0)
+    _CPU_JOBS["cfg"] = cfg
     _CPU_JOBS["feats"] = [None if c == 0 else rng.standard_normal((1, c, nn)).astype(np.float32)
-                          for c, nn in zip(sa_stack.RPN_FEAT_CHANNELS, (n_points,) + sa_stack.RPN_NPOINTS[:-1])]
+                          for c, nn in zip(cfg["feat_channels"], (n_points,) + tuple(cfg["npoints"][:-1]))]
     for s in seeds:
         _CPU_JOBS[s] = synth.scenes(kind, 1, n_points, seed=s).numpy()
 
@@ -85,15 +103,14 @@ def _cpu_prepare(kind, n_points, seeds):
 def _cpu_scene_seconds(seed):
     """the oracle's scalar port of the same op stack on one prepared scene; returns its CPU seconds"""
     import numpy as np
-    from epnet_amd import sa_stack
     from oracle import oracle
-    feats, cur = _CPU_JOBS["feats"], _CPU_JOBS[seed]
+    feats, cur, cfg = _CPU_JOBS["feats"], _CPU_JOBS[seed], _CPU_JOBS["cfg"]
     t0 = time.perf_counter()
-    for lvl, m in enumerate(sa_stack.RPN_NPOINTS):
+    for lvl, m in enumerate(cfg["npoints"]):
         cur_t = np.ascontiguousarray(cur.transpose(0, 2, 1))
         idx = oracle.furthest_point_sampling(cur, m)
         new_xyz = np.ascontiguousarray(oracle.gather_points(cur_t, idx).transpose(0, 2, 1))
-        for radius, ns in zip(sa_stack.RPN_RADII[lvl], sa_stack.RPN_NSAMPLES[lvl]):
+        for radius, ns in zip(cfg["radii"][lvl], cfg["nsamples"][lvl]):
             bq = oracle.ball_query(radius, ns, cur, new_xyz)
             oracle.group_points(cur_t, bq)
             if feats[lvl] is not None:
@@ -102,26 +119,26 @@ def _cpu_scene_seconds(seed):
     return time.perf_counter() - t0
 
 
-def cpu_baseline(kind, n_points, scenes):
+def cpu_baseline(kind, n_points, scenes, cfg):
     """one core: `scenes` scenes one after the other"""
     from oracle import oracle
     oracle.build()
     seeds = [1000 + s for s in range(scenes)]
-    _cpu_prepare(kind, n_points, seeds)
+    _cpu_prepare(kind, n_points, seeds, cfg)
     t_total = sum(_cpu_scene_seconds(s) for s in seeds)
     return {"value": scenes * n_points / t_total, "unit": "points/s", "cores": 1, "kind": "port",
-            "sample": "%d %s scenes of %d points through the same 4-level SA op stack, oracle/epnet_oracle.c, "
-                      "%.1f s of CPU time on %d-core host" % (scenes, kind, n_points, t_total, os.cpu_count())}
+            "sample": "%d %s scenes of %d points through the same %d-level SA op stack, oracle/epnet_oracle.c, "
+                      "%.1f s of CPU time on %d-core host" % (scenes, kind, n_points, len(cfg["npoints"]), t_total, os.cpu_count())}
 
 
-def cpu_baseline_multicore(kind, n_points, procs):
+def cpu_baseline_multicore(kind, n_points, procs, cfg, per_proc=2):
     """the same port, one scene per worker process at a time (the stack shards by scene on the CPU too); the
     workers are forked BEFORE this process touches the GPU and inherit the prepared inputs"""
     import multiprocessing as mp
     from oracle import oracle
     oracle.build()
-    seeds = [2000 + s for s in range(2 * procs)]
-    _cpu_prepare(kind, n_points, seeds)
+    seeds = [2000 + s for s in range(per_proc * procs)]
+    _cpu_prepare(kind, n_points, seeds, cfg)
     with mp.get_context("fork").Pool(procs) as pool:
         pool.map(_cpu_scene_seconds, seeds[:procs], chunksize=1)   # start-up: workers load the oracle
         t0 = time.perf_counter()
@@ -325,8 +342,9 @@ def main():
     # CPU baselines first: the multi-core one forks workers, which must happen before this process touches the GPU
     cpu = cpu_multi = None
     if rank == 0 and world == 1 and args.cpu_scenes > 0:
-        cpu_multi = cpu_baseline_multicore(args.kind, args.points, max(1, min(16, os.cpu_count() or 1)))
-        cpu = cpu_baseline(args.kind, args.points, args.cpu_scenes)
+        cpu_multi = cpu_baseline_multicore(args.kind, args.points, max(1, min(16, os.cpu_count() or 1)), args.cfg,
+                                           per_proc=2 if args.config == 2 else 1)
+        cpu = cpu_baseline(args.kind, args.points, args.cpu_scenes, args.cfg)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
     # one process per GPU. EPNET_BENCH_DEVICE / EPNET_BENCH_BACKEND exist only to rehearse the N > 1 code
@@ -346,14 +364,20 @@ def main():
             scene_shard.barrier()
             torch.cuda.synchronize()
 
-    def time_stack(batch, steps, warmup):
+    def time_stack(batch, steps, warmup, cfg=None, with_fp=None, pipelined=None):
         """returns (seconds for `steps` steps, the stack, its input)"""
+        cfg = args.cfg if cfg is None else cfg
+        with_fp = args.with_fp if with_fp is None else with_fp
+        pipelined = bool(args.pipelined) if pipelined is None else pipelined
+        points = args.points if cfg is args.cfg else cfg["n"]
         ids = scene_shard.scene_ids(batch * world, rank, world)           # round-robin shard of the global batch
         fn = {"ubox": synth.ubox_cloud, "kitti": synth.kitti_like_cloud, "dup": synth.dup_cloud}[args.kind]
-        xyz = torch.stack([fn(args.points, scene_shard.scene_seed(1, i)) for i in ids]).to(dev)  # inputs resident in HBM
-        stack = sa_stack.SAStack(batch, n=args.points, device=dev, with_fp=args.with_fp, seed=rank,
+        xyz = torch.stack([fn(points, scene_shard.scene_seed(1, i)) for i in ids]).to(dev)  # inputs resident in HBM
+        stack = sa_stack.SAStack(batch, n=points, device=dev, with_fp=with_fp, seed=rank,
+                                 npoints=cfg["npoints"], radii=cfg["radii"], nsamples=cfg["nsamples"],
+                                 feat_channels=cfg["feat_channels"],
                                  overlap=not args.no_overlap, fused=not args.unfused,
-                                 shared_index=not args.no_shared_index, pipelined=bool(args.pipelined),
+                                 shared_index=not args.no_shared_index, pipelined=pipelined,
                                  fused_sampling=not args.module_sampling)
         if args.no_graph:
             step = lambda: stack.step(xyz)
@@ -432,13 +456,49 @@ def main():
     roofline = roof(dominant, fps_note if dominant.startswith("fps") else grp_note)
     hbm_label = max((k for k in kernels if not k.startswith("fps")), key=lambda k: kernels[k]["step_ms"])
     roofline_hbm = roof(hbm_label, grp_note if hbm_label.startswith("group") else "")
-    stack_bytes = sa_stack.sa_algorithmic_bytes(args.points)["total"] + (sa_stack.fp_algorithmic_bytes()["total"] if args.with_fp else 0)
+    stack_bytes = (sa_stack.sa_algorithmic_bytes(args.points, args.cfg["npoints"], args.cfg["nsamples"], args.cfg["feat_channels"])["total"]
+                   + (sa_stack.fp_algorithmic_bytes()["total"] if args.with_fp else 0))
     stack_gbs = (value / args.points) * stack_bytes / 1e9 / world
 
     sweep = {}
     for bsz in [int(x) for x in args.sweep.split(",") if x]:
         e, _, _ = time_stack(bsz, args.steps, args.warmup)
         sweep[str(bsz)] = {"ms_per_step": round(e / args.steps * 1e3, 4), "points_per_s": round(bsz * args.points * args.steps / e, 1)}
+
+    # ---- further lines of the same run (N = 1, default configuration only), each verified against the oracle like the
+    # headline: the single-scene latency, the step with the FP ops, and BASELINE config 5
+    extras = {}
+    if world == 1 and args.config == 2 and not args.with_fp and args.extras:
+        del stack, xyz
+        torch.cuda.empty_cache()
+
+        def extra(name, batch, steps, cfg=None, with_fp=False, pipelined=None, note=""):
+            cfg_ = args.cfg if cfg is None else cfg
+            e, st, _x = time_stack(batch, steps, max(2, args.warmup // 2), cfg=cfg_, with_fp=with_fp, pipelined=pipelined)
+            torch.cuda.synchronize()
+            bad = verify_scene(st, st.static_xyz if st.static_xyz is not None else _x, 0) if args.verify_scenes > 0 else None
+            pts = cfg_["n"]
+            nbytes = (sa_stack.sa_algorithmic_bytes(pts, cfg_["npoints"], cfg_["nsamples"], cfg_["feat_channels"])["total"]
+                      + (sa_stack.fp_algorithmic_bytes()["total"] if with_fp else 0))
+            rate = batch * pts * steps / e
+            extras[name] = {"scenes_per_gpu": batch, "points_per_scene": pts, "steps": steps, "ms_per_step": round(e / steps * 1e3, 4),
+                            "points_per_s": round(rate, 1), "stack_algorithmic_GBps": round(rate / pts * nbytes / 1e9, 2),
+                            "stack_hbm_frac": round(rate / pts * nbytes / 1e9 / HBM_PEAK_GBS, 6),
+                            "verified": None if bad is None else not bad, "mismatches": bad or [], "workload": note}
+            del st, _x
+            torch.cuda.empty_cache()
+
+        names = [x for x in args.extras.split(",") if x]
+        if "b1" in names:
+            extra("latency_one_scene", 1, args.steps, pipelined=False,
+                  note="ONE 16384-point scene through the 4-level stack, every step alone (HIP-graph replay): the latency figure")
+        if "with_fp" in names:
+            extra("with_fp", args.batch, args.steps, with_fp=True,
+                  note="the headline step + the 4 three_nn + 4 three_interpolate of the FP modules (SA+FP = 88 087 040 B per scene)")
+        if "config5" in names:
+            extra("config5", 64, max(3, args.steps // 4), cfg=sa_stack.CONFIGS[5],
+                  note="BASELINE config 5: dense 65536-point kitti-like scenes, one level -- scene index, FPS 16384, ball query "
+                       "r 0.5 / nsample 64, grouping of coordinates and 64 feature channels (python bench.py --config 5 for the full line)")
 
     # achievable secondary denominator: a plain device-to-device copy of 2 GiB on this box
     src = torch.empty((1 << 29,), dtype=torch.float32, device=dev)
@@ -454,16 +514,24 @@ def main():
     del src, dst
 
     if rank == 0:
+        levels = len(args.cfg["npoints"])
+        if args.config == 2:
+            shape = ("the 4-level SA op stack (4 FPS + 4 gather + 8 ball_query + 8 fused groupings [xyz - centre ; features]%s), "
+                     "pyramid 16384>4096>1024>256>64, radii [[.1,.5],[.5,1],[1,2],[2,4]], nsample [16,32], C=0/96/256/512"
+                     % (" + 4 three_nn + 4 three_interpolate" if args.with_fp else ""))
+        else:
+            shape = ("one SA level (BASELINE config 5): scene index, FPS %d>%d, gather, ball_query r=%g nsample=%d, fused grouping "
+                     "[xyz - centre ; %d feature channels]" % (args.points, args.cfg["npoints"][0], args.cfg["radii"][0][0],
+                                                               args.cfg["nsamples"][0][0], args.cfg["feat_channels"][0]))
         line = {
-            "metric": "SA-stack points/sec per GPU (16384-pt KITTI scene) + % HBM roofline",
+            "metric": ("SA-stack points/sec per GPU (16384-pt KITTI scene) + % HBM roofline" if args.config == 2 else
+                       "SA-level points/sec per GPU (dense 65536-pt scene, BASELINE config 5) + % HBM roofline"),
             "value": round(value, 1), "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%d x %d-pt %s scenes per GPU per step through the 4-level SA op stack "
-                                   "(4 FPS + 4 gather + 8 ball_query + 8 fused groupings [xyz - centre ; features]%s), pyramid 16384>4096>1024>256>64, "
-                                   "radii [[.1,.5],[.5,1],[1,2],[2,4]], nsample [16,32], C=0/96/256/512, %s launch"
-                                   % (args.batch, args.points, args.kind, " + 4 three_nn + 4 three_interpolate" if args.with_fp else "",
-                                      "eager" if args.no_graph else "HIP-graph"),
+            "config": {"workload": "%d x %d-pt %s scenes per GPU per step through %s, %s launch"
+                                   % (args.batch, args.points, args.kind, shape, "eager" if args.no_graph else "HIP-graph"),
+                       "baseline_config": args.config, "levels": levels,
                        "scenes_per_gpu": args.batch, "software_pipelined": bool(args.pipelined), "points_per_scene": args.points, "parallelism": "scene-parallel x%d" % world},
             "points_per_s_per_gpu": round(value / world, 1),
             "stack_algorithmic_GBps_per_gpu": round(stack_gbs, 2), "stack_hbm_frac": round(stack_gbs / HBM_PEAK_GBS, 6),
@@ -477,6 +545,7 @@ def main():
             line["cpu_baseline_note"] = "the CPU baseline is timed in the N = 1 run only (rank 0 there has the host to itself)"
         if sweep:
             line["sweep"] = sweep
+        line.update(extras)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

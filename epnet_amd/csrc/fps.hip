@@ -628,7 +628,7 @@ __global__ __launch_bounds__(64 * kW) void fps_indexed_kernel(int n, int m, cons
 
 // ---- scenes beyond the register file (16384 < N <= 65536), over a scene index ------------------------
 // The points stay in the index (L2-resident, <= 1 MB) and the running distances in the caller's temp buffer;
-// only the bucket summaries live in registers: thread q owns bucket q (64 consecutive sorted points) -- its
+// only the bucket summaries live in registers: lane j of wave w owns bucket j * 16 + w (64 consecutive sorted points) -- its
 // box (from the index), its maximum running distance bm and the rank and coordinates of the point holding it.
 // A round tests all buckets against the new sample with the same exact lower bound, re-reads and updates only
 // the active buckets (one wave per bucket, a coalesced 1 KB row of the index), and finds the arg-max over the
@@ -645,7 +645,8 @@ __device__ int g_dbg[4096];
 __global__ __launch_bounds__(kBigThreads) void fps_bigscene_kernel(int n, int np, int m, const float *__restrict__ xyz,
                                                                   const float4 *__restrict__ sorted,
                                                                   const float *__restrict__ boxes,
-                                                                  float *__restrict__ temp, int *__restrict__ idxs) {
+                                                                  float *__restrict__ temp, float *__restrict__ tsort,
+                                                                  int *__restrict__ idxs) {
     __shared__ unsigned long long s_key[3];
     __shared__ float4 s_rec[2][16];
     __shared__ int s_idx[kIdxBufP];
@@ -656,63 +657,85 @@ __global__ __launch_bounds__(kBigThreads) void fps_bigscene_kernel(int n, int np
     sorted += (size_t)blockIdx.x * np;
     boxes += (size_t)blockIdx.x * nb * 6;
     temp += (size_t)blockIdx.x * n;
+    tsort += (size_t)blockIdx.x * np;
     idxs += (size_t)blockIdx.x * m;
     const int kNeg1 = __float_as_int(-1.f);
+    constexpr int kWaves = kBigThreads / 64;
+    // Bucket j of this wave is bucket (j * 16 + wave) of the scene: consecutive buckets of the sorted order are spatial
+    // neighbours, and a new sample touches a handful of neighbouring buckets -- dealt round-robin they land on different
+    // waves, which re-read them side by side instead of one wave working through them one L2 round trip after the other
+    // (65536 -> 16384 samples: 2.26 -> ... us per round with the distances in sorted order and two buckets per trip)
+    auto bid = [&](int j) { return (j << 4) | wave; };
+    static_assert(kWaves == 16, "bucket dealing assumes 16 waves");
 
-    const bool own = q < nb;
+    const bool own = bid(lane) < nb;
     float lox = 0.f, hix = 0.f, loy = 0.f, hiy = 0.f, loz = 0.f, hiz = 0.f;
     if (own) {
-        const float *bx = boxes + q * 6;
+        const float *bx = boxes + bid(lane) * 6;
         lox = bx[0]; hix = bx[1]; loy = bx[2]; hiy = bx[3]; loz = bx[4]; hiz = bx[5];
     }
     int bm = kNeg1;             // maximum running distance of my bucket (bits); -1: nothing real in it
     unsigned brank = 0xFFFFu;   // reference rank of the point holding it
     float bxx = 0.f, byy = 0.f, bzz = 0.f;
 
-    // original indices of this wave's 64 x 64 points, two per register: with them at hand a bucket's coordinates
-    // and its running distances are fetched side by side instead of one L2 round trip after the other
-    // (positions >= n are padding: the sort puts them last)
+    // original indices of this wave's 64 x 64 points, two per register (positions >= n are padding: the sort puts them last)
     typedef int veck __attribute__((ext_vector_type(32)));
     veck kk;
 #pragma unroll
     for (int j = 0; j < 64; j += 2) {
-        const int p0 = (((wave << 6) + j) << 6) + lane, p1 = p0 + 64;
+        const int p0 = (bid(j) << 6) + lane, p1 = (bid(j + 1) << 6) + lane;
         const unsigned k0 = p0 < n ? (unsigned)__float_as_int(sorted[p0].w) : 0xFFFFu;
         const unsigned k1 = p1 < n ? (unsigned)__float_as_int(sorted[p1].w) : 0xFFFFu;
         kk[j >> 1] = (int)(k0 | (k1 << 16));
     }
+    auto k_of = [&](int j) { return (int)(((unsigned)kk[j >> 1] >> ((j & 1) << 4)) & 0xFFFFu); };
 
-    // (re)computes the summary of bucket bb of this wave; with `update`, first lowers its distances by the sample c
-    auto refresh = [&](int bb, bool update, float cx, float cy, float cz) {
-        const int j = bb & 63;
-        const int pos = (bb << 6) + lane;
-        const int k = (int)(((unsigned)kk[j >> 1] >> ((j & 1) << 4)) & 0xFFFFu);
+    // The caller's running distances are indexed by ORIGINAL point number: a bucket's 64 values would be 64 cache lines.
+    // The rounds keep them in SORTED order instead, in the sampling scratch at the tail of the scene index (one 256-byte
+    // row per bucket, fetched beside the bucket's 1 KB row of the index); gathered on the way in, scattered back on the
+    // way out.
+    for (int j = 0; j < 64; ++j) {
+        const int pos = (bid(j) << 6) + lane;
+        if (pos < n) tsort[pos] = temp[k_of(j)];
+    }
+
+    struct Row {
+        float4 p;
+        int t;
+    };
+    auto load_row = [&](int j) {
+        Row r;
+        const int pos = (bid(j) << 6) + lane;
+        r.p = sorted[pos];
+        r.t = pos < n ? __float_as_int(tsort[pos]) : kNeg1;
+        return r;
+    };
+    // (re)computes the summary of bucket j of this wave from its row; with `update`, first lowers its distances by the sample c
+    auto finish = [&](int j, Row r, bool update, float cx, float cy, float cz) {
+        const int pos = (bid(j) << 6) + lane;
+        const int k = k_of(j);
         const bool real = pos < n;
-        const float4 p = sorted[pos];
-        int t = kNeg1;
-        if (real) {
-            t = __float_as_int(temp[k]);
-            if (update) {
-                const float dx = p.x - cx, dy = p.y - cy, dz = p.z - cz;
-                const float d = dx * dx + dy * dy + dz * dz;
-                const int tn = min(__float_as_int(d), t);  // == fminf(d, temp[k])
-                if (tn != t) temp[k] = __int_as_float(tn);
-                t = tn;
-            }
+        int t = r.t;
+        if (real && update) {
+            const float dx = r.p.x - cx, dy = r.p.y - cy, dz = r.p.z - cz;
+            const float d = dx * dx + dy * dy + dz * dz;
+            const int tn = min(__float_as_int(d), t);  // == fminf(d, temp[k])
+            if (tn != t) tsort[pos] = __int_as_float(tn);
+            t = tn;
         }
         const int mx = wave_max_all(t);
-        const unsigned r = (t == mx && real) ? rank16(k) : 0xFFFFFFFFu;
-        unsigned long long holders = __ballot(r != 0xFFFFFFFFu);
+        const unsigned rk = (t == mx && real) ? rank16(k) : 0xFFFFFFFFu;
+        unsigned long long holders = __ballot(rk != 0xFFFFFFFFu);
         unsigned rwin = 0xFFFFu;
         int wl = 0;
         if (holders) {
-            if (holders & (holders - 1ull)) holders = __ballot(r == wave_min_all(r));  // several: the smallest rank
+            if (holders & (holders - 1ull)) holders = __ballot(rk == wave_min_all(rk));  // several: the smallest rank
             wl = (int)__builtin_ctzll(holders);
-            rwin = (unsigned)__builtin_amdgcn_readlane((int)r, wl);
+            rwin = (unsigned)__builtin_amdgcn_readlane((int)rk, wl);
         }
-        const float wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.x), wl));
-        const float wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.y), wl));
-        const float wz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.z), wl));
+        const float wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.p.x), wl));
+        const float wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.p.y), wl));
+        const float wz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.p.z), wl));
         if (lane == j) {
             bm = mx;
             brank = rwin;
@@ -720,10 +743,8 @@ __global__ __launch_bounds__(kBigThreads) void fps_bigscene_kernel(int n, int np
         }
     };
 
-    for (int j = 0; j < 64; ++j) {
-        const int bb = (wave << 6) + j;
-        if (bb < nb) refresh(bb, false, 0.f, 0.f, 0.f);  // wave-uniform
-    }
+    for (int j = 0; j < 64; ++j)
+        if (bid(j) < nb) finish(j, load_row(j), false, 0.f, 0.f, 0.f);  // wave-uniform
     if (q < 3) s_key[q] = 0ull;
     if (q == 0) s_idx[0] = 0;  // rank 0 == point 0
     float cx = xyz[0], cy = xyz[1], cz = xyz[2];
@@ -742,11 +763,18 @@ __global__ __launch_bounds__(kBigThreads) void fps_bigscene_kernel(int n, int np
         const float L = bdx * bdx + bdy * bdy + bdz * bdz;
         unsigned long long active = __ballot(own && __float_as_int(L) < bm);
         stale = stale || active != 0ull;
-        // B. re-read and update them
+        // B. re-read and update them, two rows per trip to L2
         while (active) {
-            const int j = (int)__builtin_ctzll(active);
+            const int j0 = (int)__builtin_ctzll(active);
             active &= active - 1ull;
-            refresh((wave << 6) + j, true, cx, cy, cz);
+            const bool two = active != 0ull;
+            const int j1 = two ? (int)__builtin_ctzll(active) : j0;
+            active &= active - 1ull;  // (no-op on 0)
+            const Row r0 = load_row(j0);
+            Row r1 = r0;
+            if (two) r1 = load_row(j1);
+            finish(j0, r0, true, cx, cy, cz);
+            if (two) finish(j1, r1, true, cx, cy, cz);
         }
         // C. this wave's best bucket (ties by rank)
 #ifdef EPNET_BIG_NOCACHE
@@ -792,14 +820,12 @@ __global__ __launch_bounds__(kBigThreads) void fps_bigscene_kernel(int n, int np
         const int base = (m - 1) & ~(kIdxBufP - 1);
         for (int e = lane; base + e < m; e += 64) idxs[base + e] = unrank16((unsigned)s_idx[e]);
     }
-#ifdef EPNET_BIG_DEBUG
-    if (blockIdx.x == 0) {
-        g_dbg[q] = bm;
-        g_dbg[1024 + q] = (int)brank;
-        g_dbg[2048 + q] = publisher ? 1 : 0;
-        g_dbg[3072 + q] = wbest;
+    // the running distances back into the caller's order (a wave reads only what it wrote itself)
+    __builtin_amdgcn_s_setprio(0);
+    for (int j = 0; j < 64; ++j) {
+        const int pos = (bid(j) << 6) + lane;
+        if (pos < n) temp[k_of(j)] = tsort[pos];
     }
-#endif
 }
 
 }  // namespace pruned
@@ -1001,7 +1027,7 @@ static int fps_over_index(int b, int n, int m, const float *xyz, const void *ind
             EPNET_REQUIRE(xyz);
             const int np = scene_index_np(n);
             hipLaunchKernelGGL(pruned::fps_bigscene_kernel, grid, dim3(pruned::kBigThreads), 0, s, n, np, m, xyz, sorted,
-                               (const float *)(sorted + (size_t)b * np), temp, idx);
+                               (const float *)(sorted + (size_t)b * np), temp, scene_index_sampling_scratch(b, n, index), idx);
         } else {
             const int wide = getenv("EPNET_FPS_WIDE") ? atoi(getenv("EPNET_FPS_WIDE")) : 0;
             // the centres can come out of the sampling kernel itself (kCtr: the round's winner is in registers anyway) or from a

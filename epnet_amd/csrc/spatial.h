@@ -202,10 +202,16 @@ inline int scene_index_np(int n) {
     while (np < n) np <<= 1;
     return np;
 }
+// scenes beyond 16384 points: np floats more per scene at the end -- scratch of the sampling kernel (its running distances
+// in sorted order); nothing else reads or writes that tail
 inline size_t scene_index_bytes(int b, int n) {
     if (b <= 0 || n < 1024 || n > 65536) return 0;
     const size_t np = (size_t)scene_index_np(n);
-    return (size_t)b * (np * sizeof(float4) + (np / 64 + np / 256) * 6 * sizeof(float));
+    return (size_t)b * (np * sizeof(float4) + (np / 64 + np / 256) * 6 * sizeof(float) + (n > 16384 ? np * sizeof(float) : 0));
+}
+inline float *scene_index_sampling_scratch(int b, int n, const void *index) {
+    const size_t np = (size_t)scene_index_np(n);
+    return (float *)((char *)const_cast<void *>(index) + (size_t)b * (np * sizeof(float4) + (np / 64 + np / 256) * 6 * sizeof(float)));
 }
 
 // defined in ball_query.hip

@@ -33,6 +33,15 @@ RPN_FEAT_CHANNELS = (0, 96, 256, 512)  # channels of the features grouped at eac
 RPN_FP = ((1024, 64, 256), (512, 256, 1024), (512, 1024, 4096), (256, 4096, 16384))
 
 
+# the workloads bench.py times, by BASELINE.json config number: 2 = the RPN pyramid on 16384-point scenes (the metric's own
+# configuration), 5 = one SA level on dense 65536-point scenes (centres = FPS 16384, r 0.5, nsample 64, grouping of the
+# coordinates and of 64 feature channels: the ball-query / HBM stress case)
+CONFIGS = {
+    2: dict(n=16384, npoints=RPN_NPOINTS, radii=RPN_RADII, nsamples=RPN_NSAMPLES, feat_channels=RPN_FEAT_CHANNELS),
+    5: dict(n=65536, npoints=(16384,), radii=((0.5,),), nsamples=((64,),), feat_channels=(64,)),
+}
+
+
 def sa_algorithmic_bytes(n=16384, npoints=RPN_NPOINTS, nsamples=RPN_NSAMPLES, feat_channels=RPN_FEAT_CHANNELS):
     """compulsory fp32/int32 traffic of one scene through the SA op stack (each input read once, each
     output written once), per kernel family -- SURVEY.md section 8(d)"""

@@ -192,7 +192,9 @@ int epnet_feature_gather_grad(int b, int c, int h, int w, int n, int align_corne
  * shared by the sampling and both ball queries of that level (the reference has no counterpart: every one of
  * its kernels scans all n points). Results are identical to the plain entry points.
  * epnet_scene_index_bytes returns 0 where no index applies; the *_indexed entry points then (or with
- * index == NULL) run the plain path.
+ * index == NULL) run the plain path. For n > 16384 the last part of the buffer is scratch of the sampling kernel
+ * (its running distances in sorted order): two samplings over ONE index buffer must not run concurrently there;
+ * the ball queries and three_nn never touch that part.
  * -------------------------------------------------------------------------------------- */
 size_t epnet_scene_index_bytes(int b, int n);
 int epnet_scene_index_build(int b, int n, const float *xyz, void *index, size_t index_bytes, epnet_stream_t stream);

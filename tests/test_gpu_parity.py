@@ -1069,3 +1069,25 @@ def test_the_benchs_own_configuration_against_the_oracle(oracle, with_fp, kind):
     # the checker does notice a wrong buffer
     stack.levels[1]["scales"][0]["idx"][0, 5, 3] += 1
     assert bench.verify_scene(stack, stack.static_xyz, 0) == ["level2.r0.5.ball_idx"]
+
+
+def test_config5_stack_against_the_oracle(oracle):
+    """BASELINE config 5 at full size, as `bench.py --config 5` runs it (software-pipelined HIP graphs): dense 65536-point
+    scenes, FPS 16384 over the scene index (the big-scene kernel with its sorted-order running distances), ball query
+    r 0.5 / nsample 64, fused grouping of the coordinates and 64 feature channels -- every tensor against the oracle"""
+    import bench
+    from epnet_amd import sa_stack, synth
+    cfg = sa_stack.CONFIGS[5]
+    b = 2
+    xyz = synth.scenes("kitti", b, cfg["n"], seed=55).to(DEV)
+    stack = sa_stack.SAStack(b, n=cfg["n"], device=DEV, npoints=cfg["npoints"], radii=cfg["radii"], nsamples=cfg["nsamples"],
+                             feat_channels=cfg["feat_channels"], seed=6, pipelined=True, fused_sampling=True)
+    stack.capture(xyz)
+    for L in stack.levels:
+        L["fps_idx"].fill_(-1)
+        for S in L["scales"]:
+            S["grouped"].fill_(float("nan"))
+    for _ in range(3):
+        stack.replay()
+    torch.cuda.synchronize()
+    assert bench.verify_scene(stack, stack.static_xyz, 1) == []
