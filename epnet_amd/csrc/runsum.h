@@ -212,43 +212,54 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(int c, int n, int row
         }
         if (g + 1 < g_end) fetch(g + 1);  // in flight while this group is summed
         __syncthreads();
+        // the rows of grad_points this thread will add to, requested before the sums so that the read-modify-write at the
+        // end does not wait for them
+        const int n4 = n >> 2;
+        const bool have_old = vec_out && q < nr * n4;
+        float4 oldv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (have_old) oldv = reinterpret_cast<const float4 *>(gp + (size_t)(c0 + q / n4) * n)[q - (q / n4) * n4];
+        // Branch-free walk over the thread's entries: EVERY entry stores the running sum of its run -- to the output row
+        // slot of its target, or, while the thread is still inside the run its range began in, to the hand-over slot; a later
+        // entry of the same run overwrites the slot with the more complete sum, so after the last entry the slot holds the
+        // run's sum over this thread's range. (A run's slot in s_out is written by one thread only: the one it starts in.)
         float acc[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = 0.f;
         bool first_open = open_start;
+        uint4 e4 = ent4[q];
+        float4 w4 = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (W) w4 = w4p[q];
         for (int gi = 0; gi < nq; ++gi) {
-            const uint4 e4 = ent4[gi * kThreads + q];
-            float4 w4 = {1.f, 1.f, 1.f, 1.f};
-            if (W) w4 = w4p[gi * kThreads + q];
+            uint4 en = e4;
+            float4 wn = w4;
+            if (gi + 1 < nq) {  // the next four entries are on their way while these are summed
+                en = ent4[(gi + 1) * kThreads + q];
+                if (W) wn = w4p[(gi + 1) * kThreads + q];
+            }
             const unsigned es[4] = {e4.x, e4.y, e4.z, e4.w};
             const float ws[4] = {w4.x, w4.y, w4.z, w4.w};
+            float v[4][R];  // all reads of the group before any store (the stores go to the same LDS array: the compiler
+                            // would otherwise keep every read behind the previous entry's store)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int r = 0; r < R; ++r) v[k][r] = s_row[r * row_floats + (int)(es[k] & 0xFFFFu)];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const unsigned e = es[k];
-                const int pos = (int)(e & 0xFFFFu);
+                const int key = (int)((e >> 16) & 0x7FFFu);
+                const bool end = (int)e < 0;
+                const int slot = first_open ? (int)(s_first - s_out) + q : key;   // index relative to s_out, row 0
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const float v = s_row[r * row_floats + pos];
-                    acc[r] += W ? v * ws[k] : v;
+                    acc[r] += W ? v[k][r] * ws[k] : v[k][r];
+                    s_out[(first_open ? r * kThreads : r * n_pad) + slot] = acc[r];
+                    acc[r] = end ? 0.f : acc[r];
                 }
-                if (e >> 31) {
-                    const int key = (int)((e >> 16) & 0x7FFFu);
-                    if (first_open) {
-#pragma unroll
-                        for (int r = 0; r < R; ++r) s_first[r * kThreads + q] = acc[r];
-                        first_open = false;
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < R; ++r) s_out[r * n_pad + key] = acc[r];
-                    }
-#pragma unroll
-                    for (int r = 0; r < R; ++r) acc[r] = 0.f;
-                }
+                first_open = first_open && !end;
             }
-        }
-        if (whole) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) s_first[r * kThreads + q] = acc[r];
+            e4 = en;
+            w4 = wn;
         }
         __syncthreads();
         if (head) {  // collect the links of the run up to the thread it ends in
@@ -267,12 +278,11 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(int c, int n, int row
         __syncthreads();
         // grad_points += the output rows; the LDS copies go back to zero for the next group
         if (vec_out) {
-            const int n4 = n >> 2;
             for (int i = q; i < nr * n4; i += kThreads) {
                 const int r = i / n4, j4 = i - r * n4;
                 float4 *so = reinterpret_cast<float4 *>(s_out + r * n_pad) + j4;
                 float4 *dst = reinterpret_cast<float4 *>(gp + (size_t)(c0 + r) * n) + j4;
-                const float4 a = *so, o = *dst;
+                const float4 a = *so, o = (i == q && have_old) ? oldv : *dst;
                 *dst = make_float4(o.x + a.x, o.y + a.y, o.z + a.z, o.w + a.w);
                 *so = make_float4(0.f, 0.f, 0.f, 0.f);
             }

@@ -105,6 +105,27 @@ class Atten_Fusion_Conv(nn.Module):
         return F.relu(self.bn1(self.conv1(torch.cat([point_features, weighted], dim=1))))
 
 
+class UpsampleDeConv(nn.ConvTranspose2d):
+    """``nn.ConvTranspose2d`` with kernel_size == stride (the reference's DeConv layers, :165-167: kernels 2 / 4 / 8 / 16):
+    the output tiles do not overlap, so the layer is one dense product over the channels followed by a pixel shuffle --
+    out[b, co, h*k+i, w*k+j] = sum_ci x[b, ci, h, w] * W[ci, co, i, j] + bias[co]. Same parameters (names, shapes) and the
+    same values as the stock layer up to summation order; computed this way because MIOpen's first-call kernel search for
+    the 16 x 16 / stride-16 transposed convolution takes ~340 s on an MI355X box (8 x 8: ~48 s), measured -- the dense
+    product goes to rocBLAS. Stock PyTorch ops either way."""
+
+    def forward(self, x, output_size=None):
+        k = self.kernel_size[0]
+        plain = (self.kernel_size == self.stride and self.kernel_size[0] == self.kernel_size[1] and self.padding == (0, 0)
+                 and self.output_padding == (0, 0) and self.dilation == (1, 1) and self.groups == 1 and output_size is None)
+        if not plain:
+            return super().forward(x, output_size)
+        b, ci, h, w = x.shape
+        weight = self.weight.reshape(ci, -1)                                   # (ci, co * k * k), channel order (co, i, j)
+        y = torch.matmul(weight.t(), x.reshape(b, ci, h * w)).view(b, -1, h, w)
+        y = F.pixel_shuffle(y, k)
+        return y if self.bias is None else y + self.bias.view(1, -1, 1, 1)
+
+
 def stock_feature_gather(feature_map, xy):
     """the reference's ``Feature_Gather`` (:107-120) on the stock op, with the behaviour its torch version had"""
     return F.grid_sample(feature_map, xy.unsqueeze(1), mode="bilinear", padding_mode="zeros", align_corners=True).squeeze(2)
@@ -132,8 +153,8 @@ class Pointnet2MSG(nn.Module):
                 ic, pc = cfg.img_channels[i + 1], cfg.point_channels[i]
                 self.Img_Block.append(BasicBlock(cfg.img_channels[i], ic, stride=1))
                 self.Fusion_Conv.append(Atten_Fusion_Conv(ic, pc, pc) if cfg.attention else Fusion_Conv(ic + pc, pc))
-                self.DeConv.append(nn.ConvTranspose2d(ic, cfg.deconv_reduce[i], kernel_size=cfg.deconv_kernels[i],
-                                                      stride=cfg.deconv_kernels[i]))
+                self.DeConv.append(UpsampleDeConv(ic, cfg.deconv_reduce[i], kernel_size=cfg.deconv_kernels[i],
+                                                  stride=cfg.deconv_kernels[i]))
             quarter = cfg.img_features_channel // 4
             self.image_fusion_conv = nn.Conv2d(sum(cfg.deconv_reduce), quarter, kernel_size=1)
             self.image_fusion_bn = nn.BatchNorm2d(quarter)

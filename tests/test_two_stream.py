@@ -75,6 +75,29 @@ def test_names_shapes_and_size_match_the_reference_model():
     assert n_param == ref["parameters"] == 14131949           # 56.5 MB of the step's 62.7 MB gradient volume
 
 
+@pytest.mark.parametrize("k,ci,co", [(2, 8, 5), (4, 16, 16), (16, 32, 3)])
+def test_upsampling_deconvolution_equals_the_stock_layer(k, ci, co):
+    """the DeConv layers (kernel == stride) as dense product + pixel shuffle: same parameters, values and gradients as
+    nn.ConvTranspose2d"""
+    from epnet_amd.rpn_backbone import UpsampleDeConv
+    torch.manual_seed(k)
+    mine, stock = UpsampleDeConv(ci, co, kernel_size=k, stride=k), torch.nn.ConvTranspose2d(ci, co, kernel_size=k, stride=k)
+    stock.load_state_dict(mine.state_dict())
+    x = torch.randn(2, ci, 3, 5, requires_grad=True)
+    x2 = x.detach().clone().requires_grad_(True)
+    ya, yb = mine(x), stock(x2)
+    torch.testing.assert_close(ya, yb, rtol=1e-5, atol=1e-5)
+    g = torch.randn_like(ya)
+    ya.backward(g)
+    yb.backward(g)
+    torch.testing.assert_close(x.grad, x2.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(mine.weight.grad, stock.weight.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(mine.bias.grad, stock.bias.grad, rtol=1e-4, atol=1e-3)
+    # anything but the non-overlapping case falls through to the stock implementation
+    odd = UpsampleDeConv(4, 4, kernel_size=3, stride=2)
+    assert tuple(odd(torch.randn(1, 4, 5, 5)).shape) == (1, 4, 11, 11)
+
+
 @pytest.mark.parametrize("sampler", ["stock", "hip"])
 def test_reduced_model_reproduces_the_reference_on_cpu(monkeypatch, oracle, sampler):
     """host logic: the forward's wiring (xy normalisation in place, FPS-index gather of the pixel coordinates, fusion
