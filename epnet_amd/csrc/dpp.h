@@ -59,4 +59,20 @@ __device__ __forceinline__ float wave_minf_all(float v) {
 }
 __device__ __forceinline__ float wave_maxf_all(float v) { return -wave_minf_all(-v); }
 
+// float min / max over each row of 16 lanes, result in every lane of the row
+__device__ __forceinline__ float row16_minf(float v) {
+    v = fminf(v, __int_as_float(dpp_i32<0xB1>(__float_as_int(v))));
+    v = fminf(v, __int_as_float(dpp_i32<0x4E>(__float_as_int(v))));
+    v = fminf(v, __int_as_float(dpp_i32<0x124>(__float_as_int(v))));
+    v = fminf(v, __int_as_float(dpp_i32<0x128>(__float_as_int(v))));
+    return v;
+}
+__device__ __forceinline__ float row16_maxf(float v) {
+    v = fmaxf(v, __int_as_float(dpp_i32<0xB1>(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_i32<0x4E>(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_i32<0x124>(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_i32<0x128>(__float_as_int(v))));
+    return v;
+}
+
 }  // namespace epnet

@@ -297,17 +297,40 @@ __global__ __launch_bounds__(kNnTileThreads) void three_nn_tile_kernel(int n, in
             d0 = lt0 ? db : d0;               i0 = lt0 ? k : i0;
         }
     };
+    // A known bucket covers a 4x larger region than a bucket of unknowns (the known set is the 4x sparser FPS subset), so most of
+    // its 64 points are out of reach even when the bucket's box is not: the box of each ROW of 16 consecutive points (compact:
+    // the points are in spatial order) is found on the fly with four DPP steps per coordinate, and a row is offered only if
+    // some lane's exact lower bound to that box is within its third distance (three_nn of a 256-scene step 1.5 -> ... ms)
     auto scan = [&](int kb) {
+        const float4 kp = sorted_k[((size_t)kb << 6) + lane];  // one coalesced row, then broadcast reads out of LDS
         __builtin_amdgcn_wave_barrier();
-        pts[lane] = sorted_k[((size_t)kb << 6) + lane];  // one coalesced row, then broadcast reads out of LDS
+        pts[lane] = kp;
         __builtin_amdgcn_wave_barrier();
-#pragma unroll 4
-        for (int j = 0; j < 64; j += 4) {
-            const float4 p0 = pts[j], p1 = pts[j + 1], p2 = pts[j + 2], p3 = pts[j + 3];
-            offer(p0);
-            offer(p1);
-            offer(p2);
-            offer(p3);
+        // padding rows carry 3e38: they only widen a row's box (never a wrong skip); non-finite points are never offered
+        const float rlx = row16_minf(kp.x), rhx = row16_maxf(kp.x), rly = row16_minf(kp.y), rhy = row16_maxf(kp.y),
+                    rlz = row16_minf(kp.z), rhz = row16_maxf(kp.z);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float blx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rlx), r * 16));
+            const float bhx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rhx), r * 16));
+            const float bly = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rly), r * 16));
+            const float bhy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rhy), r * 16));
+            const float blz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rlz), r * 16));
+            const float bhz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rhz), r * 16));
+            const float px = __builtin_amdgcn_fmed3f(u.x, blx, bhx), py = __builtin_amdgcn_fmed3f(u.y, bly, bhy),
+                        pz = __builtin_amdgcn_fmed3f(u.z, blz, bhz);
+            const float ex = u.x - px, ey = u.y - py, ez = u.z - pz;
+            const float Lf = ex * ex + ey * ey + ez * ez;  // same expression as the distance: a lower bound of every point's
+            // (a NaN bound -- non-finite coordinates -- compares false and keeps the row)
+            if (!__ballot(valid && !(Lf > __uint_as_float(d2 == kNone ? 0x7F800000u : d2)))) continue;
+#pragma unroll
+            for (int j = r * 16; j < r * 16 + 16; j += 4) {
+                const float4 p0 = pts[j], p1 = pts[j + 1], p2 = pts[j + 2], p3 = pts[j + 3];
+                offer(p0);
+                offer(p1);
+                offer(p2);
+                offer(p3);
+            }
         }
     };
 
@@ -462,6 +485,70 @@ __global__ __launch_bounds__(kTiThreads) void three_interpolate_lds_kernel(int c
     }
 }
 
+// Same, with the staged rows interleaved FOUR channels to a known point ([m][4] floats per group of four rows): one 16-byte
+// LDS read then serves four channel rows -- a quarter of the LDS instructions and less than half the LDS cycles per output
+// byte of the row-major kernel above (random 4-byte reads: two 32-lane groups over 32 banks; random 16-byte reads: four
+// 16-lane groups over 16 bank quads), which is what bounded it (3.5 TB/s against 5.2 for a plain gather).
+// rows is a multiple of 4 (c % 4 == 0), m % 4 == 0, n % 4 == 0; dynamic LDS: rows * m floats.
+__global__ __launch_bounds__(kTiThreads) void three_interpolate_lds4_kernel(int c, int m, int n, int rows, int tile,
+                                                                            const float *__restrict__ points,
+                                                                            const int *__restrict__ idx,
+                                                                            const float *__restrict__ weight,
+                                                                            float *__restrict__ out) {
+    extern __shared__ float4 s_quad[];  // [rows / 4][m] float4 = the four channels of one known point
+    const int bs = blockIdx.z;
+    const int c0 = blockIdx.y * rows;
+    const int nr = min(rows, c - c0);  // multiple of 4
+    const int groups = nr >> 2, m4 = m >> 2;
+    const float *src = points + ((size_t)bs * c + c0) * m;
+    for (int e = threadIdx.x; e < groups * m4; e += kTiThreads) {
+        const int g = e / m4, j4 = e - g * m4;
+        const float4 *row = reinterpret_cast<const float4 *>(src + (size_t)g * 4 * m) + j4;
+        const float4 a = row[0], b4 = row[m4], cc = row[2 * m4], d = row[3 * m4];
+        float4 *dst = s_quad + g * m + j4 * 4;
+        dst[0] = make_float4(a.x, b4.x, cc.x, d.x);
+        dst[1] = make_float4(a.y, b4.y, cc.y, d.y);
+        dst[2] = make_float4(a.z, b4.z, cc.z, d.z);
+        dst[3] = make_float4(a.w, b4.w, cc.w, d.w);
+    }
+    __syncthreads();
+    const int i_begin = blockIdx.x * tile, i_end = min(n, i_begin + tile);
+    float *dst_base = out + ((size_t)bs * c + c0) * n;
+    for (int i0 = i_begin + threadIdx.x * 4; i0 < i_end; i0 += kTiThreads * 4) {
+        int ix[4][3];
+        float w[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                ix[u][j] = idx[((size_t)bs * n + i0 + u) * 3 + j];
+                w[u][j] = weight[((size_t)bs * n + i0 + u) * 3 + j];
+            }
+        const float4 *quad = s_quad;
+        float *dst = dst_base + i0;
+        for (int g = 0; g < groups; ++g) {
+            float4 v[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) v[u][j] = quad[ix[u][j]];
+            // the reference's expression per output: w0 * p0 + w1 * p1 + w2 * p2, left to right (interpolate_gpu.cu:95-96)
+#define EPNET_TI_ROW(F_)                                                                                      \
+    store_stream(dst, w[0][0] * v[0][0].F_ + w[0][1] * v[0][1].F_ + w[0][2] * v[0][2].F_,                     \
+                 w[1][0] * v[1][0].F_ + w[1][1] * v[1][1].F_ + w[1][2] * v[1][2].F_,                          \
+                 w[2][0] * v[2][0].F_ + w[2][1] * v[2][1].F_ + w[2][2] * v[2][2].F_,                          \
+                 w[3][0] * v[3][0].F_ + w[3][1] * v[3][1].F_ + w[3][2] * v[3][2].F_);                         \
+    dst += n;
+            EPNET_TI_ROW(x)
+            EPNET_TI_ROW(y)
+            EPNET_TI_ROW(z)
+            EPNET_TI_ROW(w)
+#undef EPNET_TI_ROW
+            quad += m;
+        }
+    }
+}
+
 // gradient: rows of grad_points (m floats each) accumulated in LDS, see group.hip
 __global__ __launch_bounds__(kTiThreads) void three_interpolate_grad_lds_kernel(int c, int n, int m, int rows,
                                                                                 const float *__restrict__ grad_out,
@@ -534,6 +621,7 @@ extern "C" int epnet_three_interpolate(int b, int c, int m, int n, const float *
         int rows = kLdsBudget / (m * 4);
         if (rows > c) rows = c;
         if (rows > 32) rows = 32;
+        if ((c & 3) == 0 && rows >= 4) rows &= ~3;  // whole groups of four channels for the interleaved kernel
         const int chunks = div_up(c, rows);
         int tiles = div_up(1024, b * chunks);
         const int max_tiles = n / 2048;
@@ -543,8 +631,12 @@ extern "C" int epnet_three_interpolate(int b, int c, int m, int n, const float *
         tile = (tile + 1023) / 1024 * 1024;
         tiles = div_up(n, tile);
         if (chunks <= 65535) {
-            hipLaunchKernelGGL(three_interpolate_lds_kernel, dim3(tiles, chunks, b), dim3(kTiThreads), (size_t)rows * m * 4,
-                               (hipStream_t)stream, c, m, n, rows, tile, points, idx, weight, out);
+            if ((c & 3) == 0 && (m & 3) == 0 && (rows & 3) == 0 && ((uintptr_t)points & 15) == 0)
+                hipLaunchKernelGGL(three_interpolate_lds4_kernel, dim3(tiles, chunks, b), dim3(kTiThreads), (size_t)rows * m * 4,
+                                   (hipStream_t)stream, c, m, n, rows, tile, points, idx, weight, out);
+            else
+                hipLaunchKernelGGL(three_interpolate_lds_kernel, dim3(tiles, chunks, b), dim3(kTiThreads), (size_t)rows * m * 4,
+                                   (hipStream_t)stream, c, m, n, rows, tile, points, idx, weight, out);
             return check_launch("three_interpolate");
         }
     }
@@ -605,8 +697,6 @@ extern "C" int epnet_three_nn_ws(int b, int n, int m, const float *unknown, cons
     return check_launch("three_nn indexed");
 }
 
-// runs the unknowns are cut into: the fewest (power of two) that let 8 rows of one run fit LDS, as long as the
-// inverse index keeps at most 16384 keys
 // atomic-free gradient (runsum.h): the 3n (unknown, neighbour) pairs grouped by their known point once, then equal shares
 // of the sorted pairs summed per thread (w * grad_out) out of LDS-staged grad_out rows
 extern "C" size_t epnet_three_interpolate_grad_workspace_bytes(int b, int n, int m) {
