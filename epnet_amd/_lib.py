@@ -31,6 +31,8 @@ SIGNATURES = {
     "epnet_group_points": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "epnet_group_points_grad": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "epnet_group_concat": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "epnet_group_concat_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "epnet_group_concat_ws": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "epnet_group_concat_grad": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "epnet_group_points_grad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "epnet_group_points_grad_ws": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -399,6 +399,77 @@ __global__ __launch_bounds__(kGThreads) void group_linear_grad_w_kernel(int c, i
     }
 }
 
+// ---- rows too long for LDS (n * 4 > 64 KB: the 65536-point scenes of BASELINE config 5) -----------------------------
+// The channel-major gather above then reads 4 bytes per lane from 64 different cache lines per instruction and is bound by
+// the texture addresser (2.2 TB/s on C = 64, N = 65536). With caller scratch the features are turned point-major once
+// (b, n, c): a position's c channels are one contiguous row, fetched with 16-byte loads into an LDS tile of 256 positions
+// and written back out transposed, 256 contiguous bytes per channel row and wave. Extra traffic: the features once more
+// (c * n * 8 bytes per scene against c * p * 4 of output, p = npoints * nsample >> n).
+constexpr int kPmThreads = 256;
+constexpr int kPmTile = 256;  // positions per workgroup
+
+__global__ __launch_bounds__(256) void transpose_cn_kernel(int c, int n, const float *__restrict__ src, float *__restrict__ dst) {
+    __shared__ float tile[64][65];
+    const int bs = blockIdx.z, n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    src += (size_t)bs * c * n;
+    dst += (size_t)bs * c * n;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4)
+        if (c0 + r < c && n0 + tx < n) tile[r][tx] = src[(size_t)(c0 + r) * n + n0 + tx];
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4)
+        if (n0 + r < n && c0 + tx < c) dst[(size_t)(n0 + r) * c + c0 + tx] = tile[tx][r];
+}
+
+// points_t (b, n, c) point-major; out rows (b, c, p) with row stride ostride between scenes; c % 4 == 0, c <= 128
+__global__ __launch_bounds__(kPmThreads) void gather_rows_pm_kernel(int c, int n, int p, size_t ostride,
+                                                                    const float *__restrict__ points_t,
+                                                                    const int *__restrict__ idx, float *__restrict__ out) {
+    extern __shared__ float s_tile[];  // [kPmTile][c + 1]: the odd stride keeps the transposed reads conflict-free
+    const int bs = blockIdx.y, q0 = blockIdx.x * kPmTile;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int cs = c + 1, lanes_per_row = c >> 2, rows_per_pass = kPmThreads / lanes_per_row;
+    points_t += (size_t)bs * n * c;
+    idx += (size_t)bs * p;
+    out += (size_t)bs * ostride;
+    const int cnt = min(kPmTile, p - q0);
+    const int r_in = t / lanes_per_row, l_in = t - r_in * lanes_per_row;
+    if (r_in < rows_per_pass)
+        for (int r = r_in; r < cnt; r += rows_per_pass) {
+            const int j = idx[q0 + r];
+            const float4 v = reinterpret_cast<const float4 *>(points_t + (size_t)j * c)[l_in];
+            float *d = s_tile + r * cs + l_in * 4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    __syncthreads();
+    for (int ch = wave; ch < c; ch += kPmThreads / 64) {
+        float *dst = out + (size_t)ch * p + q0;
+#pragma unroll
+        for (int k = 0; k < kPmTile / 64; ++k) {
+            const int r = k * 64 + lane;
+            if (r < cnt) __builtin_nontemporal_store(s_tile[r * cs + ch], dst + r);
+        }
+    }
+}
+
+static size_t gather_pm_ws_bytes(int b, int c, int n, long long p) {
+    constexpr int kLdsBudget = EPNET_GATHER_LDS_BUDGET_KB * 1024;
+    if (b <= 0 || c < 16 || c > 128 || (c & 3) || (size_t)n * 4 <= (size_t)kLdsBudget || p < (long long)n) return 0;  // (few positions: the copy would cost more than it saves)
+    return (size_t)b * c * n * sizeof(float);
+}
+
+static int launch_gather_rows_pm(int b, int c, int n, long long p, const float *points, const int *idx, float *out, size_t ostride,
+                                 void *workspace, hipStream_t s, const char *what) {
+    if (b > 65535 || p > 0x7fffffffll) return EPNET_ELIMIT;
+    float *pt = (float *)workspace;
+    hipLaunchKernelGGL(transpose_cn_kernel, dim3(div_up(n, 64), div_up(c, 64), b), dim3(256), 0, s, c, n, points, pt);
+    int rc = check_launch("feature transpose");
+    if (rc) return rc;
+    hipLaunchKernelGGL(gather_rows_pm_kernel, dim3((unsigned)div_up64(p, kPmTile), b), dim3(kPmThreads),
+                       (size_t)kPmTile * (c + 1) * sizeof(float), s, c, n, (int)p, ostride, pt, idx, out);
+    return check_launch(what);
+}
+
 static int launch_gather_rows(int b, int c, int n, long long p, const float *points, const int *idx, float *out,
                               hipStream_t s, const char *what, size_t ostride = 0) {
     if (ostride == 0) ostride = (size_t)c * (size_t)p;
@@ -441,8 +512,8 @@ static int launch_gather_rows(int b, int c, int n, long long p, const float *poi
 // ---- scatter-add without atomics (runsum.h): the positions grouped by target once, then equal shares of the sorted
 // entries summed per thread out of LDS-staged grad_out rows
 static size_t scatter_ws_bytes(int b, int n, long long p) {
-    if (b <= 0 || !runsum::usable(n, p, p)) return 0;
-    return runsum::workspace_bytes(b, p, false);
+    if (b <= 0 || !runsum::usable(n, 1, p, p)) return 0;
+    return runsum::workspace_bytes(b, n, 1, p, false);
 }
 
 static int launch_scatter_rows_csr(int b, int c, int n, long long p, const float *grad_out, const int *idx,
@@ -451,8 +522,8 @@ static int launch_scatter_rows_csr(int b, int c, int n, long long p, const float
     if (gstride == 0) gstride = (size_t)c * (size_t)p;
     if (b == 0 || c == 0 || p == 0 || n == 0) return EPNET_OK;
     if (!(grad_out && idx && grad_points && workspace)) return EPNET_EINVAL;
-    return runsum::launch<false>(b, c, n, (int)p, 1, (int)p, grad_out, gstride, idx, nullptr, grad_points, workspace,
-                                 workspace_bytes, s, what);
+    return runsum::launch<false>(b, c, n, 1, (int)p, grad_out, gstride, idx, nullptr, grad_points, workspace, workspace_bytes, s,
+                                 what);
 }
 
 static int launch_scatter_rows(int b, int c, int n, long long p, const float *grad_out, const int *idx,
@@ -508,6 +579,18 @@ extern "C" int epnet_group_points_grad(int b, int c, int n, int npoints, int nsa
                                "group_points_grad");
 }
 
+// the three centred coordinate rows of a grouped tensor whose scenes are ostride floats apart
+static int launch_group_xyz(int b, int n, int npoints, int nsample, long long p, size_t ostride, const float *xyz,
+                            const float *new_xyz, const int *idx, float *out, hipStream_t s) {
+    if (nsample % 4 == 0 && (((uintptr_t)idx | (uintptr_t)out) % 16 == 0) && (ostride % 4 == 0))
+        hipLaunchKernelGGL(group_xyz_centred_vec4_kernel, dim3((unsigned)div_up64(p / 4, kGThreads), b), dim3(kGThreads), 0, s, n,
+                           npoints, nsample, ostride, xyz, new_xyz, idx, out);
+    else
+        hipLaunchKernelGGL(group_xyz_centred_kernel, dim3((unsigned)div_up64(p, kGThreads), b), dim3(kGThreads), 0, s, n, npoints,
+                           nsample, ostride, xyz, new_xyz, idx, out);
+    return check_launch("group_concat xyz");
+}
+
 extern "C" int epnet_group_concat(int b, int c, int n, int npoints, int nsample, const float *xyz, const float *new_xyz,
                                   const float *features, const int *idx, float *out, int use_xyz, epnet_stream_t stream) {
     EPNET_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0 && nsample >= 0);
@@ -521,17 +604,37 @@ extern "C" int epnet_group_concat(int b, int c, int n, int npoints, int nsample,
     const int ch0 = use_xyz ? 3 : 0;
     const size_t ostride = (size_t)(ch0 + c) * (size_t)p;
     if (use_xyz) {
-        if (nsample % 4 == 0 && (((uintptr_t)idx | (uintptr_t)out) % 16 == 0) && (ostride % 4 == 0))
-            hipLaunchKernelGGL(group_xyz_centred_vec4_kernel, dim3((unsigned)div_up64(p / 4, kGThreads), b), dim3(kGThreads), 0,
-                               s, n, npoints, nsample, ostride, xyz, new_xyz, idx, out);
-        else
-            hipLaunchKernelGGL(group_xyz_centred_kernel, dim3((unsigned)div_up64(p, kGThreads), b), dim3(kGThreads), 0, s, n,
-                               npoints, nsample, ostride, xyz, new_xyz, idx, out);
-        int rc = check_launch("group_concat xyz");
+        int rc = launch_group_xyz(b, n, npoints, nsample, p, ostride, xyz, new_xyz, idx, out, s);
         if (rc) return rc;
     }
     if (c == 0) return EPNET_OK;
     return launch_gather_rows(b, c, n, p, features, idx, out + (size_t)ch0 * p, s, "group_concat features", ostride);
+}
+
+extern "C" size_t epnet_group_concat_workspace_bytes(int b, int c, int n, int npoints, int nsample) {
+    return gather_pm_ws_bytes(b, c, n, (long long)npoints * nsample);
+}
+
+// epnet_group_concat with caller scratch of epnet_group_concat_workspace_bytes bytes (0: no scratch helps this shape)
+extern "C" int epnet_group_concat_ws(int b, int c, int n, int npoints, int nsample, const float *xyz, const float *new_xyz,
+                                     const float *features, const int *idx, float *out, int use_xyz, void *workspace,
+                                     size_t workspace_bytes, epnet_stream_t stream) {
+    const long long p = (long long)npoints * nsample;
+    const size_t need = gather_pm_ws_bytes(b, c, n, p);
+    if (need == 0 || !workspace || ((uintptr_t)workspace & 15))
+        return epnet_group_concat(b, c, n, npoints, nsample, xyz, new_xyz, features, idx, out, use_xyz, stream);
+    if (workspace_bytes < need) return EPNET_ENOMEM;
+    EPNET_REQUIRE(b >= 0 && n > 0 && npoints >= 0 && nsample >= 0 && features && idx && out && (!use_xyz || (xyz && new_xyz)));
+    if (p > 0x7fffffffll || b > 65535) return EPNET_ELIMIT;
+    // the coordinate rows as usual, then the feature rows through the point-major copy
+    const int ch0 = use_xyz ? 3 : 0;
+    const size_t ostride = (size_t)(ch0 + c) * (size_t)p;
+    if (use_xyz) {
+        int rc = launch_group_xyz(b, n, npoints, nsample, p, ostride, xyz, new_xyz, idx, out, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return launch_gather_rows_pm(b, c, n, p, features, idx, out + (size_t)ch0 * p, ostride, workspace, (hipStream_t)stream,
+                                 "group_concat features");
 }
 
 // the groupings of the nscales scales of an MSG level (same points, same features) in one call: out[k] (b, 3+c | c,

@@ -700,8 +700,8 @@ extern "C" int epnet_three_nn_ws(int b, int n, int m, const float *unknown, cons
 // atomic-free gradient (runsum.h): the 3n (unknown, neighbour) pairs grouped by their known point once, then equal shares
 // of the sorted pairs summed per thread (w * grad_out) out of LDS-staged grad_out rows
 extern "C" size_t epnet_three_interpolate_grad_workspace_bytes(int b, int n, int m) {
-    if (b <= 0 || !runsum::usable(m, (long long)n * 3, n)) return 0;
-    return runsum::workspace_bytes(b, (long long)n * 3, true);
+    if (b <= 0 || !runsum::usable(m, 3, (long long)n * 3, n)) return 0;
+    return runsum::workspace_bytes(b, m, 3, n, true);
 }
 
 extern "C" int epnet_three_interpolate_grad_ws(int b, int c, int n, int m, const float *grad_out, const int *idx,
@@ -713,7 +713,7 @@ extern "C" int epnet_three_interpolate_grad_ws(int b, int c, int n, int m, const
     EPNET_REQUIRE(b >= 0 && c >= 0);
     if (b == 0 || c == 0) return EPNET_OK;
     EPNET_REQUIRE(grad_out && idx && weight && grad_points && workspace);
-    return runsum::launch<true>(b, c, m, n * 3, 3, n, grad_out, (size_t)c * n, idx, weight, grad_points, workspace, workspace_bytes,
+    return runsum::launch<true>(b, c, m, 3, n, grad_out, (size_t)c * n, idx, weight, grad_points, workspace, workspace_bytes,
                                 (hipStream_t)stream, "three_interpolate_grad");
 }
 

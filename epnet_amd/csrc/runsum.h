@@ -6,7 +6,7 @@
 // Two kernels, both over caller scratch:
 //   pack_kernel     groups the entries of a scene by their target once (counting sort in LDS, `parts` workgroups per
 //                   scene, each owning a range of targets) into 32-bit words  end << 31 | key << 16 | pos, `end` marking
-//                   the last entry of a target's run; the array is padded to a multiple of 4096 with entries of a dump
+//                   the last entry of a target's run; the array is padded to a multiple of 4096 with one-entry runs of a dump
 //                   target and stored blocked-transposed, so that thread q of the sum kernel owns the sorted slots
 //                   [q * ept, (q + 1) * ept) and still reads them with coalesced 16-byte loads.
 //   scatter_kernel  one 1024-thread workgroup walks a sequence of channel-row groups of one scene. Per group: the R rows of
@@ -41,9 +41,20 @@ __host__ __device__ inline int slot_to_mem(int s, int ept) {
     return (((i >> 2) * kThreads) + q) * 4 + (i & 3);
 }
 
-inline bool usable(int n, long long entries, long long row_floats) {
-    return n >= 1 && n <= kMaxTargets && entries >= 1 && entries <= kMaxEntries && row_floats >= 4 && row_floats <= kMaxRowFloats &&
-           row_floats % 4 == 0;
+// Rows longer than the LDS budget are worked off in TILES of positions (a launch pair per tile, each adding to grad_points):
+// the longest tile whose single row fits beside the output row of n targets and the hand-over slots.
+inline int tile_floats(int n, int div, long long row_floats) {
+    const long long n_pad = (n + 1 + 3) / 4 * 4;
+    long long t = ((long long)kLdsLimit / 4 - n_pad - kThreads);
+    if (t > kMaxRowFloats) t = kMaxRowFloats;
+    if (t * div > kMaxEntries) t = kMaxEntries / div;
+    if (t >= row_floats) return (int)row_floats;   // one tile
+    return (int)(t / kChunk * kChunk);             // whole chunks of 4096 positions (0: does not fit)
+}
+
+inline bool usable(int n, int div, long long entries, long long row_floats) {
+    return n >= 1 && n <= kMaxTargets && entries >= 1 && entries == row_floats * div && row_floats >= 4 && row_floats % 4 == 0 &&
+           row_floats <= (1 << 22) && tile_floats(n, div, row_floats) >= 4;
 }
 
 inline size_t lds_bytes(int rows, int n, int row_floats) {
@@ -60,15 +71,17 @@ inline int pick_rows(int b, int c, int n, int row_floats) {
     return rows;
 }
 
-inline size_t workspace_bytes(int b, long long entries, bool weighted) {
-    return (size_t)b * (size_t)padded_entries((int)entries) * (weighted ? 8 : 4);
+// (n, div, row_floats as for usable(): the scratch holds the sorted entries of ONE tile of every scene)
+inline size_t workspace_bytes(int b, int n, int div, long long row_floats, bool weighted) {
+    const long long tile = tile_floats(n, div, row_floats);
+    return (size_t)b * (size_t)padded_entries((int)(tile * div)) * (weighted ? 8 : 4);
 }
 
 // ---- the inverse index -------------------------------------------------------------------------------------------
-// grid (parts, b). idx: (b, p) targets, clamped into [0, n) (an index outside is undefined behaviour in the reference;
+// grid (parts, b). idx: p targets per scene, clamped into [0, n) (an index outside is undefined behaviour in the reference;
 // here it cannot leave the scene). pos of entry t = t / div (div = 3: the three neighbours of an unknown point).
 template <bool W>
-__global__ __launch_bounds__(kThreads) void pack_kernel(int n, int p, int div, const int *__restrict__ idx,
+__global__ __launch_bounds__(kThreads) void pack_kernel(int n, int p, int div, size_t idx_stride, const int *__restrict__ idx,
                                                         const float *__restrict__ weight, unsigned *__restrict__ ent,
                                                         float *__restrict__ wsorted) {
     extern __shared__ int s_bins[];  // counts (nb), then run starts (nb + 1)
@@ -77,10 +90,10 @@ __global__ __launch_bounds__(kThreads) void pack_kernel(int n, int p, int div, c
     const int q = threadIdx.x, lane = q & 63, wave = q >> 6;
     const int parts = gridDim.x, part = blockIdx.x, bs = blockIdx.y;
     const int P = padded_entries(p), ept = P / kThreads;
-    idx += (size_t)bs * p;
+    idx += (size_t)bs * idx_stride;   // p entries of this tile; the scenes are idx_stride entries apart
     ent += (size_t)bs * P;
     if (W) {
-        weight += (size_t)bs * p;
+        weight += (size_t)bs * idx_stride;
         wsorted += (size_t)bs * P;
     }
     const int nb = (n + parts - 1) / parts;
@@ -134,19 +147,21 @@ __global__ __launch_bounds__(kThreads) void pack_kernel(int n, int p, int div, c
         ent[at] = end | ((unsigned)j << 16) | (unsigned)(t / div);
         if (W) wsorted[at] = weight[t];
     }
-    if (part == parts - 1)  // padding: one run of a dump target (key n) that reads position 0 with weight 0
-        for (int s = p + q; s < P; s += kThreads) {
+    if (part == parts - 1)  // padding: entries of a dump target (key n) that read position 0 with weight 0, every one a run
+        for (int s = p + q; s < P; s += kThreads) {  // of its own (ONE long run would be handed from thread to thread)
             const int at = slot_to_mem(s, ept);
-            ent[at] = (s == P - 1 ? 0x80000000u : 0u) | ((unsigned)n << 16);
+            ent[at] = 0x80000000u | ((unsigned)n << 16);
             if (W) wsorted[at] = 0.f;
         }
 }
 
 // ---- the sums ----------------------------------------------------------------------------------------------------
 // grid (workgroups per scene, b); workgroup x takes the row groups [x * per_wg, (x + 1) * per_wg) of its scene.
-// grad_out rows of a scene: grad_out + bs * gstride + row * row_floats; grad_points rows: ((bs * c) + row) * n.
+// grad_out rows of a scene: row_floats floats at grad_out + bs * gstride + row * row_stride (row_stride > row_floats: one tile
+// of longer rows); grad_points rows: ((bs * c) + row) * n.
 template <int R, bool W>
-__global__ __launch_bounds__(kThreads) void scatter_kernel(int c, int n, int row_floats, int P, int per_wg, int vec_out, size_t gstride,
+__global__ __launch_bounds__(kThreads) void scatter_kernel(int c, int n, int row_floats, int row_stride, int P, int per_wg, int vec_out,
+                                                           size_t gstride,
                                                            const float *__restrict__ grad_out,
                                                            const unsigned *__restrict__ ent,
                                                            const float *__restrict__ wsorted,
@@ -179,8 +194,29 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(int c, int n, int row
     const bool whole = open_start && !any_end;  // one link of a run that began before and ends after this thread's range
     const bool head = open_end && !whole;       // the run this thread's range ends inside of begins here: finish it
     const int last_key = (int)((last >> 16) & 0x7FFFu);
+    const int first_key = q > 0 ? (int)((ent[(size_t)bs * P + slot_to_mem(q * ept - 1, ept)] >> 16) & 0x7FFFu) : 0;
     s_whole[q] = whole ? 1 : 0;
     for (int i = q; i < R * n_pad; i += kThreads) s_out[i] = 0.f;
+    __syncthreads();
+    // A run that crosses MANY threads (a target with thousands of entries) must not be collected link by link: the thread a
+    // run starts in collects at most kNear links; links further down the chain add themselves with an LDS atomic.
+    constexpr int kNear = 4;
+    bool long_chain = false;   // (head) more than kNear links follow
+    if (head) {
+        long_chain = true;
+        for (int k = q + 1; k <= q + kNear && k < kThreads; ++k)
+            if (!s_whole[k]) {
+                long_chain = false;
+                break;
+            }
+        if (q + kNear >= kThreads) long_chain = false;  // the chain ends with the last thread at the latest
+    }
+    bool far = false;          // (open_start) more than kNear links away from the thread the run starts in
+    if (open_start) {
+        int d = 1;
+        for (int k = q - 1; k >= 0 && s_whole[k] && d <= kNear; --k) ++d;
+        far = d > kNear;
+    }
 
     const float *go = grad_out + (size_t)bs * gstride;
     float *gp = grad_points + (size_t)bs * c * n;
@@ -190,12 +226,17 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(int c, int n, int row
     f4 pre[kPre];
     auto fetch = [&](int g) {
         const int nr = min(R, c - g * R);
-        const f4 *src = reinterpret_cast<const f4 *>(go + (size_t)g * R * row_floats);
+        const float *src = go + (size_t)g * R * row_stride;
         const int total4 = nr * row4;
 #pragma unroll
         for (int k = 0; k < kPre; ++k) {
             const int e = k * kThreads + q;
-            if (e < total4) pre[k] = src[e];
+            if (e < total4) {
+                const int r = (R == 1 || row_stride == row_floats) ? 0 : e / row4;
+                const int col = e - r * row4;
+                pre[k] = (R == 1 || row_stride == row_floats) ? reinterpret_cast<const f4 *>(src)[e]
+                                                              : reinterpret_cast<const f4 *>(src + (size_t)r * row_stride)[col];
+            }
         }
     };
     fetch(g_beg);
@@ -262,18 +303,21 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(int c, int n, int row
             w4 = wn;
         }
         __syncthreads();
-        if (head) {  // collect the links of the run up to the thread it ends in
+        if (head) {  // collect the (near) links of the run this thread's range ends inside of
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                float total = acc[r];
-                int k = q + 1;
-                while (k < kThreads) {
-                    total += s_first[r * kThreads + k];
+                float links = 0.f;
+                for (int k = q + 1; k <= q + kNear && k < kThreads; ++k) {
+                    links += s_first[r * kThreads + k];
                     if (!s_whole[k]) break;
-                    ++k;
                 }
-                s_out[r * n_pad + last_key] = total;
+                if (long_chain) atomicAdd(&s_out[r * n_pad + last_key], links);   // the slot holds this thread's own part already
+                else s_out[r * n_pad + last_key] = acc[r] + links;
             }
+        }
+        if (far) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) atomicAdd(&s_out[r * n_pad + first_key], s_first[r * kThreads + q]);
         }
         __syncthreads();
         // grad_points += the output rows; the LDS copies go back to zero for the next group
@@ -299,44 +343,53 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(int c, int n, int row
 }
 
 template <bool W>
-inline int launch(int b, int c, int n, int entries, int div, int row_floats, const float *grad_out, size_t gstride,
-                  const int *idx, const float *weight, float *grad_points, void *workspace, size_t workspace_bytes_given,
-                  hipStream_t s, const char *what) {
-    if (workspace_bytes_given < workspace_bytes(b, entries, W)) return EPNET_ENOMEM;
+inline int launch(int b, int c, int n, int div, int row_floats, const float *grad_out, size_t gstride, const int *idx,
+                  const float *weight, float *grad_points, void *workspace, size_t workspace_bytes_given, hipStream_t s,
+                  const char *what) {
+    if (workspace_bytes_given < workspace_bytes(b, n, div, row_floats, W)) return EPNET_ENOMEM;
     if (b > 65535) return EPNET_ELIMIT;
     if (((uintptr_t)grad_out | (uintptr_t)(gstride * sizeof(float))) & 15) return EPNET_EINVAL;  // callers check alignment first
-    const int P = padded_entries(entries);
-    unsigned *ent = (unsigned *)workspace;
-    float *wsorted = W ? (float *)(ent + (size_t)b * P) : nullptr;
+    const int tile = tile_floats(n, div, row_floats);
+    const size_t idx_stride = (size_t)row_floats * div;
     // parts: enough workgroups to spread the counting sort over the chip, each with at least a few hundred targets
     int parts = b >= 128 ? 1 : b >= 32 ? 4 : b >= 8 ? 8 : 16;
     while (parts > 1 && n / parts < 256) parts >>= 1;
     const int nb = div_up(n, parts);
-    hipLaunchKernelGGL((pack_kernel<W>), dim3(parts, b), dim3(kThreads), (size_t)(2 * nb + 1) * sizeof(int), s, n, entries, div, idx,
-                       weight, ent, wsorted);
-    int rc = check_launch("inverse index");
-    if (rc) return rc;
-    const int rows = pick_rows(b, c, n, row_floats);
-    const int groups = div_up(c, rows);
-    // about two workgroups per CU over the whole launch (one resident at a time when a row fills the LDS), whole passes
-    const size_t lds = lds_bytes(rows, n, row_floats);
-    int wgs = (lds > 80 * 1024 ? 256 : 512) / b;
-    if (wgs < 1) wgs = 1;
-    if (wgs > groups) wgs = groups;
-    const int per_wg = div_up(groups, wgs);
-    wgs = div_up(groups, per_wg);
     const int vec_out = ((n & 3) == 0 && ((uintptr_t)grad_points & 15) == 0) ? 1 : 0;
-    dim3 grid(wgs, b);
-#define EPNET_RUNSUM(R_) \
-    hipLaunchKernelGGL((scatter_kernel<R_, W>), grid, dim3(kThreads), lds, s, c, n, row_floats, P, per_wg, vec_out, gstride, grad_out, ent, wsorted, grad_points)
-    switch (rows) {
-        case 8: EPNET_RUNSUM(8); break;
-        case 4: EPNET_RUNSUM(4); break;
-        case 2: EPNET_RUNSUM(2); break;
-        default: EPNET_RUNSUM(1); break;
-    }
+    for (int pos0 = 0; pos0 < row_floats; pos0 += tile) {
+        const int len = min(tile, row_floats - pos0);  // a multiple of 4: row_floats and the tile length are
+        const int entries = len * div;
+        const int P = padded_entries(entries);
+        unsigned *ent = (unsigned *)workspace;
+        float *wsorted = W ? (float *)(ent + (size_t)b * P) : nullptr;
+        hipLaunchKernelGGL((pack_kernel<W>), dim3(parts, b), dim3(kThreads), (size_t)(2 * nb + 1) * sizeof(int), s, n, entries, div,
+                           idx_stride, idx + (size_t)pos0 * div, W ? weight + (size_t)pos0 * div : nullptr, ent, wsorted);
+        int rc = check_launch("inverse index");
+        if (rc) return rc;
+        const int rows = pick_rows(b, c, n, len);
+        const int groups = div_up(c, rows);
+        // about two workgroups per CU over the whole launch (one resident at a time when a row fills the LDS), whole passes
+        const size_t lds = lds_bytes(rows, n, len);
+        int wgs = (lds > 80 * 1024 ? 256 : 512) / b;
+        if (wgs < 1) wgs = 1;
+        if (wgs > groups) wgs = groups;
+        const int per_wg = div_up(groups, wgs);
+        wgs = div_up(groups, per_wg);
+        dim3 grid(wgs, b);
+#define EPNET_RUNSUM(R_)                                                                                                     \
+    hipLaunchKernelGGL((scatter_kernel<R_, W>), grid, dim3(kThreads), lds, s, c, n, len, row_floats, P, per_wg, vec_out, gstride, \
+                       grad_out + pos0, ent, wsorted, grad_points)
+        switch (rows) {
+            case 8: EPNET_RUNSUM(8); break;
+            case 4: EPNET_RUNSUM(4); break;
+            case 2: EPNET_RUNSUM(2); break;
+            default: EPNET_RUNSUM(1); break;
+        }
 #undef EPNET_RUNSUM
-    return check_launch(what);
+        rc = check_launch(what);
+        if (rc) return rc;
+    }
+    return EPNET_OK;
 }
 
 }  // namespace runsum

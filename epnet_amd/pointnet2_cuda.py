@@ -264,9 +264,15 @@ def group_concat_wrapper(b, c, n, npoints, nsample, xyz, new_xyz, features, idx,
         need(xyz, b * n * 3, "xyz"); need(new_xyz, b * npoints * 3, "new_xyz")
     if c:
         need(features, b * c * n, "features")
+    l = _lib.lib()
+    ws_bytes = l.epnet_group_concat_workspace_bytes(b, c, n, npoints, nsample) if c else 0
     with on_device_of(idx) as s:
-        _lib.check(_lib.lib().epnet_group_concat(b, c, n, npoints, nsample, px, pn, pf, pi, po, int(bool(use_xyz)), s),
-                   "group_concat")
+        if ws_bytes:   # rows too long for on-chip staging: scratch for a point-major copy of the features
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=idx.device)
+            _lib.check(l.epnet_group_concat_ws(b, c, n, npoints, nsample, px, pn, pf, pi, po, int(bool(use_xyz)), ws.data_ptr(),
+                                               ws_bytes, s), "group_concat")
+        else:
+            _lib.check(l.epnet_group_concat(b, c, n, npoints, nsample, px, pn, pf, pi, po, int(bool(use_xyz)), s), "group_concat")
     return 1
 
 

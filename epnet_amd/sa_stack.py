@@ -191,7 +191,7 @@ class SAStack:
 
     def _group_scales(self, L, cur_xyz, parity):
         """the groupings of all scales of the level: one call (feature rows staged once for both scales)"""
-        if self.fused and self.multi_group:
+        if self.fused and self.multi_group and len(L["scales"]) > 1:
             ext.group_concat_multi_wrapper(self.batch, L["c"], L["n"], L["m"], [S["ns"] for S in L["scales"]], cur_xyz,
                                            L["sets"][parity]["new_xyz"], L["features"], [S["idx"] for S in L["scales"]],
                                            [S["grouped"] for S in L["scales"]], True)

@@ -100,6 +100,13 @@ int epnet_group_points_grad(int b, int c, int n, int npoints, int nsample, const
  * reference composition (a gather and one fp32 subtraction). */
 int epnet_group_concat(int b, int c, int n, int npoints, int nsample, const float *xyz, const float *new_xyz,
                        const float *features, const int *idx, float *out, int use_xyz, epnet_stream_t stream);
+/* the same with caller scratch: where the feature rows are too long for on-chip staging (n > 16384 points: BASELINE config
+ * 5) the features are turned point-major once in the scratch and gathered as contiguous rows. workspace_bytes = 0 (or
+ * workspace NULL): plain epnet_group_concat. */
+size_t epnet_group_concat_workspace_bytes(int b, int c, int n, int npoints, int nsample);
+int epnet_group_concat_ws(int b, int c, int n, int npoints, int nsample, const float *xyz, const float *new_xyz,
+                          const float *features, const int *idx, float *out, int use_xyz, void *workspace,
+                          size_t workspace_bytes, epnet_stream_t stream);
 
 /* gradient of the above w.r.t. features: grad_out (B, 3+C | C, M, ns) -> grad_features (B,C,N) accumulated into */
 int epnet_group_concat_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out, const int *idx,

@@ -39,7 +39,7 @@ def test_argument_validation_without_gpu(hiplib):
     assert hiplib.epnet_ball_query(-1, 1, 1, 1.0, 1, None, None, None, None) == -1
     assert hiplib.epnet_furthest_point_sampling(1, 16, 4, None, None, None, None) == -1
     assert hiplib.epnet_group_points(1, 1, 1, 1, 1, None, None, None, None) == -1
-    assert hiplib.epnet_nms_workspace_bytes(6300) == 6300 * 99 * 8 + 6300 * 16
+    assert hiplib.epnet_nms_workspace_bytes(6300) == 6300 * 99 * 8 + 6300 * 80   # mask words + one 80-byte record per box
     assert hiplib.epnet_nms_workspace_bytes(0) == 0
     # positions to fill from an EMPTY cloud (n = 0): an error code, not a division by zero on the host
     import ctypes as C

@@ -442,6 +442,9 @@ def _skewed_indices(rng, b, n, count, mode):
     (2, 4, 1000, 1024, 4, "one"),          # exactly one chunk of entries, no padding
     (1, 3, 16384, 1025, 4, "zipf"),        # 4100 entries: 4092 padding entries of the dump target
     (2, 6, 50, 16, 4, "few"),              # 64 entries for 1024 threads: almost everything is padding
+    (2, 16, 16384, 4096, 16, "blocks"),    # level-1 shapes: rows of 65536 / 131072 positions worked off in tiles of 20480
+    (2, 5, 16384, 4096, 32, "zipf"),
+    (1, 3, 9000, 5000, 20, "uniform"),     # 100000 positions, 9000 targets: tiles of 28672
 ])
 def test_group_points_grad_uneven_lists(oracle, b, c, n, m, ns, mode):
     """the run-sum gradient (csrc/runsum.h) on neighbour lists of every shape: equal shares of the sorted entries per
@@ -1091,3 +1094,29 @@ def test_config5_stack_against_the_oracle(oracle):
         stack.replay()
     torch.cuda.synchronize()
     assert bench.verify_scene(stack, stack.static_xyz, 1) == []
+
+
+@pytest.mark.parametrize("b,c,n,m,ns", [(2, 64, 65536, 2048, 64), (1, 16, 40000, 4000, 20), (2, 128, 20000, 700, 32), (1, 20, 17000, 2001, 12)])
+def test_group_concat_long_rows_through_point_major_scratch(oracle, b, c, n, m, ns):
+    """feature rows beyond LDS (n > 16384): epnet_group_concat_ws gathers from a point-major copy of the features; identical
+    to the plain entry point and to the oracle's grouping"""
+    from epnet_amd import _lib, pointnet2_cuda as ext
+    assert _lib.lib().epnet_group_concat_workspace_bytes(b, c, n, m, ns) == b * c * n * 4
+    g = torch.Generator().manual_seed(n + c)
+    xyz = dev(rand_cloud(b, n, seed=n))
+    new_xyz = xyz[:, :m].contiguous()
+    feats = torch.randn((b, c, n), generator=g).to(DEV)
+    idx = torch.randint(0, n, (b, m, ns), generator=g, dtype=torch.int32).to(DEV)
+    out = torch.full((b, 3 + c, m, ns), float("nan"), device=DEV)
+    ext.group_concat_wrapper(b, c, n, m, ns, xyz, new_xyz, feats, idx, out, True)
+    want_feat = oracle.group_points(host(feats), host(idx))
+    np.testing.assert_array_equal(host(out[:, 3:]), want_feat)
+    want_xyz = oracle.group_points(host(xyz.transpose(1, 2).contiguous()), host(idx)) - host(new_xyz).transpose(0, 2, 1)[:, :, :, None]
+    np.testing.assert_array_equal(host(out[:, :3]), want_xyz)
+    plain = torch.empty_like(out)
+    _lib.check(_lib.lib().epnet_group_concat(b, c, n, m, ns, xyz.data_ptr(), new_xyz.data_ptr(), feats.data_ptr(), idx.data_ptr(),
+                                             plain.data_ptr(), 1, torch.cuda.current_stream().cuda_stream), "group_concat")
+    assert torch.equal(out, plain)
+    only = torch.full((b, c, m, ns), float("nan"), device=DEV)
+    ext.group_concat_wrapper(b, c, n, m, ns, None, None, feats, idx, only, False)
+    np.testing.assert_array_equal(host(only), want_feat)
