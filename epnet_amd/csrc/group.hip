@@ -14,6 +14,8 @@
 //             to grad_points with plain coalesced stores: no global atomics, no cross-workgroup
 //             races. Summation order within a row is still unspecified (as it is in the
 //             reference), so gradients are compared to 1e-5, not bit-for-bit.
+#include <stdlib.h>
+
 #include "common.h"
 #include "spatial.h"
 #include "runsum.h"
@@ -92,6 +94,43 @@ __global__ __launch_bounds__(kGThreads) void gather_rows_scalar_kernel(int c, in
 #define EPNET_GATHER_LDS_UNROLL 1
 #endif
 constexpr int kGLdsThreads = EPNET_GATHER_LDS_THREADS;
+// ---- four channel rows interleaved per LDS word ("quad" staging) ----------------------------------------------------
+// [n][4] floats per group of four rows: one 16-byte LDS read then serves four channel rows of one position -- a quarter of
+// the LDS instructions and less than half the LDS cycles of the row-major staging (random 4-byte reads: two 32-lane groups
+// over 32 banks; random 16-byte reads: four 16-lane groups over 16 bank quads). The gather shares every CU with the
+// sampling rounds of the pipelined stack, which wait on dependent LDS operations: what the gather does not put into the
+// LDS queue shortens those rounds.
+__device__ __forceinline__ void stage_quads(const float *__restrict__ src, int groups, int n, float4 *__restrict__ s_quad,
+                                            int threads) {
+    const int n4 = n >> 2;
+    for (int e = threadIdx.x; e < groups * n4; e += threads) {
+        const int g = e / n4, j4 = e - g * n4;
+        const float4 *row = reinterpret_cast<const float4 *>(src + (size_t)g * 4 * n) + j4;
+        const float4 a = row[0], b4 = row[n4], cc = row[2 * n4], d = row[3 * n4];
+        float4 *dst = s_quad + (size_t)g * n + j4 * 4;
+        dst[0] = make_float4(a.x, b4.x, cc.x, d.x);
+        dst[1] = make_float4(a.y, b4.y, cc.y, d.y);
+        dst[2] = make_float4(a.z, b4.z, cc.z, d.z);
+        dst[3] = make_float4(a.w, b4.w, cc.w, d.w);
+    }
+}
+
+// positions id.x..w of `groups` quad-staged row groups -> four channel rows of 16 bytes each per group
+__device__ __forceinline__ void serve_quads(const float4 *__restrict__ quad, int groups, int n, int4 id, float *__restrict__ dst,
+                                            int p) {
+#pragma unroll 1
+    for (int g = 0; g < groups; ++g) {
+        const float4 v0 = quad[id.x], v1 = quad[id.y], v2 = quad[id.z], v3 = quad[id.w];
+        store_stream(dst, v0.x, v1.x, v2.x, v3.x);
+        store_stream(dst + p, v0.y, v1.y, v2.y, v3.y);
+        store_stream(dst + 2 * (size_t)p, v0.z, v1.z, v2.z, v3.z);
+        store_stream(dst + 3 * (size_t)p, v0.w, v1.w, v2.w, v3.w);
+        quad += n;
+        dst += 4 * (size_t)p;
+    }
+}
+
+template <bool QUAD>  // QUAD: rows % 4 == 0 == c % 4 == n % 4, points 16-byte aligned
 __global__ __launch_bounds__(kGLdsThreads) void gather_rows_lds_kernel(int c, int n, int p, int rows, int tile, size_t ostride,
                                                                     const float *__restrict__ points,
                                                                     const int *__restrict__ idx,
@@ -102,7 +141,9 @@ __global__ __launch_bounds__(kGLdsThreads) void gather_rows_lds_kernel(int c, in
     const int nr = min(rows, c - c0);
     const float *src = points + ((size_t)bs * c + c0) * n;
     const int total = nr * n;
-    if ((n & 3) == 0 && ((uintptr_t)src & 15) == 0) {
+    if (QUAD) {
+        stage_quads(src, nr >> 2, n, reinterpret_cast<float4 *>(s_rows), kGLdsThreads);
+    } else if ((n & 3) == 0 && ((uintptr_t)src & 15) == 0) {
         const float4 *src4 = reinterpret_cast<const float4 *>(src);
         float4 *dst4 = reinterpret_cast<float4 *>(s_rows);
         EPNET_STAGE_PRAGMA
@@ -117,6 +158,10 @@ __global__ __launch_bounds__(kGLdsThreads) void gather_rows_lds_kernel(int c, in
     for (int q = q_begin + threadIdx.x * 4; q < q_end; q += kGLdsThreads * 4) {
         const int4 id = *reinterpret_cast<const int4 *>(ix + q);
         float *dst = dst_base + q;
+        if (QUAD) {
+            serve_quads(reinterpret_cast<const float4 *>(s_rows), nr >> 2, n, id, dst, p);
+            continue;
+        }
         const float *row = s_rows;
 #pragma unroll EPNET_GATHER_LDS_UNROLL
         for (int r = 0; r < nr; ++r) {
@@ -137,6 +182,7 @@ __global__ __launch_bounds__(kGLdsThreads) void gather_rows_lds_kernel(int c, in
 #endif
 // the same for the TWO scales of an MSG level at once: both gather from the same feature rows, so the rows are
 // staged once and then serve both index sets (saves one 64 KB staging pass per workgroup: 7-12 % of the traffic)
+template <bool QUAD>
 __global__ __launch_bounds__(kGLdsThreads) void gather_rows_lds2_kernel(int c, int n, int rows, const float *__restrict__ points,
                                                                         int p0, size_t ostride0, const int *__restrict__ idx0,
                                                                         float *__restrict__ out0, int p1, size_t ostride1,
@@ -147,7 +193,9 @@ __global__ __launch_bounds__(kGLdsThreads) void gather_rows_lds2_kernel(int c, i
     const int nr = min(rows, c - c0);
     const float *src = points + ((size_t)bs * c + c0) * n;
     const int total = nr * n;
-    if ((n & 3) == 0 && ((uintptr_t)src & 15) == 0) {
+    if (QUAD) {
+        stage_quads(src, nr >> 2, n, reinterpret_cast<float4 *>(s_rows), kGLdsThreads);
+    } else if ((n & 3) == 0 && ((uintptr_t)src & 15) == 0) {
         const float4 *src4 = reinterpret_cast<const float4 *>(src);
         float4 *dst4 = reinterpret_cast<float4 *>(s_rows);
         EPNET_STAGE_PRAGMA
@@ -164,6 +212,10 @@ __global__ __launch_bounds__(kGLdsThreads) void gather_rows_lds2_kernel(int c, i
         for (int q = threadIdx.x * 4; q < p; q += kGLdsThreads * 4) {
             const int4 id = *reinterpret_cast<const int4 *>(ix + q);
             float *dst = dst_base + q;
+            if (QUAD) {
+                serve_quads(reinterpret_cast<const float4 *>(s_rows), nr >> 2, n, id, dst, p);
+                continue;
+            }
             const float *row = s_rows;
 #pragma unroll EPNET_GATHER_LDS2_UNROLL
             for (int r = 0; r < nr; ++r) {
@@ -406,7 +458,7 @@ __global__ __launch_bounds__(kGThreads) void group_linear_grad_w_kernel(int c, i
 // and written back out transposed, 256 contiguous bytes per channel row and wave. Extra traffic: the features once more
 // (c * n * 8 bytes per scene against c * p * 4 of output, p = npoints * nsample >> n).
 constexpr int kPmThreads = 256;
-constexpr int kPmTile = 256;  // positions per workgroup
+constexpr int kPmTile = 128;  // positions per workgroup: 33 KB of LDS at c = 64, four workgroups per CU
 
 __global__ __launch_bounds__(256) void transpose_cn_kernel(int c, int n, const float *__restrict__ src, float *__restrict__ dst) {
     __shared__ float tile[64][65];
@@ -421,7 +473,7 @@ __global__ __launch_bounds__(256) void transpose_cn_kernel(int c, int n, const f
         if (n0 + r < n && c0 + tx < c) dst[(size_t)(n0 + r) * c + c0 + tx] = tile[tx][r];
 }
 
-// points_t (b, n, c) point-major; out rows (b, c, p) with row stride ostride between scenes; c % 4 == 0, c <= 128
+// points_t (b, n, c) point-major; out rows (b, c, p) with row stride ostride between scenes; c % 4 == 0, 16 <= c <= 128
 __global__ __launch_bounds__(kPmThreads) void gather_rows_pm_kernel(int c, int n, int p, size_t ostride,
                                                                     const float *__restrict__ points_t,
                                                                     const int *__restrict__ idx, float *__restrict__ out) {
@@ -434,13 +486,29 @@ __global__ __launch_bounds__(kPmThreads) void gather_rows_pm_kernel(int c, int n
     out += (size_t)bs * ostride;
     const int cnt = min(kPmTile, p - q0);
     const int r_in = t / lanes_per_row, l_in = t - r_in * lanes_per_row;
-    if (r_in < rows_per_pass)
-        for (int r = r_in; r < cnt; r += rows_per_pass) {
-            const int j = idx[q0 + r];
-            const float4 v = reinterpret_cast<const float4 *>(points_t + (size_t)j * c)[l_in];
-            float *d = s_tile + r * cs + l_in * 4;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    // a thread's rows r_in, r_in + rows_per_pass, ...: all indices first, then all rows in flight together (kMaxPass x 16 bytes)
+    constexpr int kMaxPass = 8;   // c >= 16: at least 64 rows per pass of 256 threads... 128 / 16 = 8 passes at c = 64
+    if (r_in < rows_per_pass) {
+        for (int r0 = r_in; r0 < cnt; r0 += rows_per_pass * kMaxPass) {
+            int j[kMaxPass];
+            float4 v[kMaxPass];
+#pragma unroll
+            for (int k = 0; k < kMaxPass; ++k) {
+                const int r = r0 + k * rows_per_pass;
+                j[k] = r < cnt ? idx[q0 + r] : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < kMaxPass; ++k) v[k] = reinterpret_cast<const float4 *>(points_t + (size_t)j[k] * c)[l_in];
+#pragma unroll
+            for (int k = 0; k < kMaxPass; ++k) {
+                const int r = r0 + k * rows_per_pass;
+                if (r < cnt) {
+                    float *d = s_tile + r * cs + l_in * 4;
+                    d[0] = v[k].x; d[1] = v[k].y; d[2] = v[k].z; d[3] = v[k].w;
+                }
+            }
         }
+    }
     __syncthreads();
     for (int ch = wave; ch < c; ch += kPmThreads / 64) {
         float *dst = out + (size_t)ch * p + q0;
@@ -483,6 +551,8 @@ static int launch_gather_rows(int b, int c, int n, long long p, const float *poi
         int rows = kLdsBudget / (n * 4);
         if (rows > c) rows = c;
         if (rows > 32) rows = 32;
+        const bool quad = (c & 3) == 0 && (n & 3) == 0 && rows >= 4 && ((uintptr_t)points & 15) == 0 && !getenv("EPNET_GATHER_NO_QUAD");
+        if (quad) rows &= ~3;  // whole groups of four channel rows
         const int chunks = div_up(c, rows);
         // enough workgroups to fill the chip; every tile re-stages its rows, so keep tiles >= 2048 positions
         int tiles = div_up(1024, b * chunks);
@@ -494,8 +564,12 @@ static int launch_gather_rows(int b, int c, int n, long long p, const float *poi
         tiles = (int)div_up64(p, tile);
         if (chunks <= 65535) {
             dim3 grid(tiles, chunks, b);
-            hipLaunchKernelGGL(gather_rows_lds_kernel, grid, dim3(kGLdsThreads), (size_t)rows * n * 4, s, c, n, (int)p, rows, tile,
-                               ostride, points, idx, out);
+            if (quad)
+                hipLaunchKernelGGL(gather_rows_lds_kernel<true>, grid, dim3(kGLdsThreads), (size_t)rows * n * 4, s, c, n, (int)p, rows,
+                                   tile, ostride, points, idx, out);
+            else
+                hipLaunchKernelGGL(gather_rows_lds_kernel<false>, grid, dim3(kGLdsThreads), (size_t)rows * n * 4, s, c, n, (int)p, rows,
+                                   tile, ostride, points, idx, out);
             return check_launch(what);
         }
     }
@@ -649,10 +723,13 @@ extern "C" int epnet_group_concat_multi(int b, int c, int n, int npoints, int ns
     constexpr int kLdsBudget = EPNET_GATHER_LDS_BUDGET_KB * 1024;
     bool fused = nscales == 2 && c >= 8 && b > 0 && n > 0 && npoints > 0 && (size_t)n * 4 <= (size_t)kLdsBudget && features && b <= 65535;
     int rows = 0;
+    bool quad = false;
     if (fused) {
         rows = kLdsBudget / (n * 4);
         if (rows > c) rows = c;
         if (rows > 32) rows = 32;
+        quad = (c & 3) == 0 && (n & 3) == 0 && rows >= 4 && ((uintptr_t)features & 15) == 0 && !getenv("EPNET_GATHER_NO_QUAD");
+        if (quad) rows &= ~3;
         for (int k = 0; k < 2 && fused; ++k) {
             const long long p = (long long)npoints * nsamples[k];
             fused = p >= 2048 && p <= 0x7fffffffll && p % 4 == 0 && idx[k] && out[k] &&
@@ -684,9 +761,14 @@ extern "C" int epnet_group_concat_multi(int b, int c, int n, int npoints, int ns
         const int rc = check_launch("group_concat_multi xyz");
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(gather_rows_lds2_kernel, dim3(div_up(c, rows), b), dim3(kGLdsThreads), (size_t)rows * n * 4, s, c, n, rows,
-                       features, pk[0], ostride[0], idx[0], out[0] + (size_t)ch0 * pk[0], pk[1], ostride[1], idx[1],
-                       out[1] + (size_t)ch0 * pk[1]);
+    if (quad)
+        hipLaunchKernelGGL(gather_rows_lds2_kernel<true>, dim3(div_up(c, rows), b), dim3(kGLdsThreads), (size_t)rows * n * 4, s, c, n,
+                           rows, features, pk[0], ostride[0], idx[0], out[0] + (size_t)ch0 * pk[0], pk[1], ostride[1], idx[1],
+                           out[1] + (size_t)ch0 * pk[1]);
+    else
+        hipLaunchKernelGGL(gather_rows_lds2_kernel<false>, dim3(div_up(c, rows), b), dim3(kGLdsThreads), (size_t)rows * n * 4, s, c, n,
+                           rows, features, pk[0], ostride[0], idx[0], out[0] + (size_t)ch0 * pk[0], pk[1], ostride[1], idx[1],
+                           out[1] + (size_t)ch0 * pk[1]);
     return check_launch("group_concat_multi");
 }
 

@@ -20,6 +20,8 @@
 // chain of dependent loads, and nothing is atomic. The order of the terms inside a run is whatever the counting sort
 // produced (the reference's atomicAdd order is unspecified as well).
 #pragma once
+#include <stdlib.h>
+
 #include "common.h"
 #include "spatial.h"
 
@@ -48,6 +50,10 @@ inline int tile_floats(int n, int div, long long row_floats) {
     long long t = ((long long)kLdsLimit / 4 - n_pad - kThreads);
     if (t > kMaxRowFloats) t = kMaxRowFloats;
     if (t * div > kMaxEntries) t = kMaxEntries / div;
+    if (const char *e = getenv("EPNET_RUNSUM_TILE")) {  // tuning: shorter tiles, more workgroups per CU
+        const long long cap = atoll(e);
+        if (cap >= kChunk && cap < t) t = cap;
+    }
     if (t >= row_floats) return (int)row_floats;   // one tile
     return (int)(t / kChunk * kChunk);             // whole chunks of 4096 positions (0: does not fit)
 }
