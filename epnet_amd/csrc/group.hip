@@ -530,12 +530,24 @@ static int launch_gather_rows_pm(int b, int c, int n, long long p, const float *
                                  void *workspace, hipStream_t s, const char *what) {
     if (b > 65535 || p > 0x7fffffffll) return EPNET_ELIMIT;
     float *pt = (float *)workspace;
-    hipLaunchKernelGGL(transpose_cn_kernel, dim3(div_up(n, 64), div_up(c, 64), b), dim3(256), 0, s, c, n, points, pt);
-    int rc = check_launch("feature transpose");
-    if (rc) return rc;
-    hipLaunchKernelGGL(gather_rows_pm_kernel, dim3((unsigned)div_up64(p, kPmTile), b), dim3(kPmThreads),
-                       (size_t)kPmTile * (c + 1) * sizeof(float), s, c, n, (int)p, ostride, pt, idx, out);
-    return check_launch(what);
+    // a few scenes at a time, so that the point-major copies are still on the chip (L2 / Infinity Cache) when they are gathered
+    // (16 scenes of C = 64, N = 65536 at once: 268 MB of copies, 3.7 TB/s; one scene: 4.0 TB/s)
+    int chunk = (int)((64ll << 20) / ((long long)c * n * 4));
+    if (chunk < 1) chunk = 1;
+    for (int b0 = 0; b0 < b; b0 += chunk) {
+        const int nb = min(chunk, b - b0);
+        const float *src = points + (size_t)b0 * c * n;
+        float *dst = pt + (size_t)b0 * c * n;
+        hipLaunchKernelGGL(transpose_cn_kernel, dim3(div_up(n, 64), div_up(c, 64), nb), dim3(256), 0, s, c, n, src, dst);
+        int rc = check_launch("feature transpose");
+        if (rc) return rc;
+        hipLaunchKernelGGL(gather_rows_pm_kernel, dim3((unsigned)div_up64(p, kPmTile), nb), dim3(kPmThreads),
+                           (size_t)kPmTile * (c + 1) * sizeof(float), s, c, n, (int)p, ostride, dst, idx + (size_t)b0 * p,
+                           out + (size_t)b0 * ostride);
+        rc = check_launch(what);
+        if (rc) return rc;
+    }
+    return EPNET_OK;
 }
 
 static int launch_gather_rows(int b, int c, int n, long long p, const float *points, const int *idx, float *out,
