@@ -170,10 +170,14 @@ def test_full_size_two_stream_backbone_against_stock_sampler(hiplib):
     # behind them renormalises by batch statistics, which amplifies that through 4 fusion levels + 4 FP levels: 5e-5 observed
     # on outputs of order 1. The tight comparison is therefore made in eval mode below; here the bound is the amplified one.
     torch.testing.assert_close(f_hip, f_stock, rtol=1e-3, atol=3e-4)
-    torch.testing.assert_close(gi_hip, gi_stock, rtol=1e-2, atol=1e-3 * float(gi_stock.abs().max()))
-    for k in gp_stock:
-        tol = 1e-3 * max(1e-6, float(gp_stock[k].abs().max()))
-        torch.testing.assert_close(gp_hip[k], gp_stock[k], rtol=1e-2, atol=tol, msg=lambda m, k=k: "%s: %s" % (k, m))
+    # gradients: a 1e-5 difference in a pre-activation that sits at zero flips its ReLU, and with it a whole path of the
+    # backward pass -- a handful of elements differ by per cent while everything else agrees to 1e-4. The bound is therefore
+    # on the relative L2 error of each gradient tensor (a wrong sampler gradient would show as O(1))
+    def rel_l2(a, b):
+        return float((a - b).norm() / b.norm().clamp_min(1e-20))
+    assert rel_l2(gi_hip, gi_stock) < 5e-3, rel_l2(gi_hip, gi_stock)
+    worst = max(((rel_l2(gp_hip[k], gp_stock[k]), k) for k in gp_stock), key=lambda t: t[0])
+    assert worst[0] < 5e-3, worst
     with torch.no_grad():
         outs = []
         for model in (hip, stock):
