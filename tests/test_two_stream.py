@@ -173,8 +173,12 @@ def test_full_size_two_stream_backbone_against_stock_sampler(hiplib):
     # gradients: a 1e-5 difference in a pre-activation that sits at zero flips its ReLU, and with it a whole path of the
     # backward pass -- a handful of elements differ by per cent while everything else agrees to 1e-4. The bound is therefore
     # on the relative L2 error of each gradient tensor (a wrong sampler gradient would show as O(1))
+    # (a bias in front of a batch norm has a gradient of exactly zero in training mode -- both sides hold rounding noise there:
+    # errors are taken relative to the tensor's own norm or, for such tensors, to 1e-3 of the largest gradient norm of the model)
+    floor = 1e-3 * max(float(g_.norm()) for g_ in gp_stock.values())
+
     def rel_l2(a, b):
-        return float((a - b).norm() / b.norm().clamp_min(1e-20))
+        return float((a - b).norm() / b.norm().clamp_min(floor))
     assert rel_l2(gi_hip, gi_stock) < 5e-3, rel_l2(gi_hip, gi_stock)
     worst = max(((rel_l2(gp_hip[k], gp_stock[k]), k) for k in gp_stock), key=lambda t: t[0])
     assert worst[0] < 5e-3, worst
