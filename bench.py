@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None,
-                    help="scenes per GPU per step (default 256 for config 2, 64 for config 5; EPNET_BENCH_BATCH overrides)")
+                    help="scenes per GPU per step (default 256 for config 2, 128 for config 5; EPNET_BENCH_BATCH overrides)")
     ap.add_argument("--config", type=int, default=2, choices=[2, 5],
                     help="BASELINE.json config: 2 = 16384-point scenes through the 4-level stack (the metric's configuration), "
                          "5 = dense 65536-point scenes, one level: FPS 16384, ball query r 0.5 / nsample 64, grouping C = 3 and 64")
@@ -78,7 +78,7 @@ def parse():
     if args.points is None:
         args.points = args.cfg["n"]
     if args.batch is None:
-        args.batch = int(os.environ.get("EPNET_BENCH_BATCH", "256" if args.config == 2 else "64"))
+        args.batch = int(os.environ.get("EPNET_BENCH_BATCH", "256" if args.config == 2 else "128"))
     if args.cpu_scenes is None:
         args.cpu_scenes = int(os.environ.get("EPNET_BENCH_CPU_SCENES", "16" if args.config == 2 else "2"))
     if args.with_fp and args.config != 2:
@@ -502,7 +502,7 @@ def main():
             extra("with_fp", args.batch, args.steps, with_fp=True,
                   note="the headline step + the 4 three_nn + 4 three_interpolate of the FP modules (SA+FP = 88 087 040 B per scene)")
         if "config5" in names:
-            extra("config5", 64, max(3, args.steps // 4), cfg=sa_stack.CONFIGS[5],
+            extra("config5", 128, max(3, args.steps // 4), cfg=sa_stack.CONFIGS[5],
                   note="BASELINE config 5: dense 65536-point kitti-like scenes, one level -- scene index, FPS 16384, ball query "
                        "r 0.5 / nsample 64, grouping of coordinates and 64 feature channels (python bench.py --config 5 for the full line)")
 

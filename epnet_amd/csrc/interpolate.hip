@@ -282,12 +282,11 @@ __global__ __launch_bounds__(kNnTileThreads) void three_nn_tile_kernel(int n, in
 
     unsigned d0 = kNone, d1 = kNone, d2 = kNone;
     int i0 = 0x7fffffff, i1 = 0x7fffffff, i2 = 0x7fffffff;
-    auto offer = [&](const float4 p) {
-        const int k = __float_as_int(p.w);
-        const float dx = u.x - p.x, dy = u.y - p.y, dz = u.z - p.z;
-        const float d = dx * dx + dy * dy + dz * dz;
-        // padding rows and non-finite distances never enter a list, as in the reference (interpolate_gpu.cu:37-48)
-        const unsigned db = (k >= 0 && d < __builtin_huge_valf()) ? __float_as_uint(d) : kNone;
+    // four known points at a time: the squared distances two to an instruction (v_pk_add_f32 / v_pk_mul_f32 round like the
+    // scalar forms: same (dx*dx + dy*dy) + dz*dz), one vote for the four, then the insertions of those that matter
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 ux2 = {u.x, u.x}, uy2 = {u.y, u.y}, uz2 = {u.z, u.z};
+    auto insert = [&](unsigned db, int k) {
         const bool lt2 = db < d2 || (db == d2 && k < i2);
         if (!__ballot(lt2 && db != kNone)) return;  // nobody's list changes
         const bool lt0 = db < d0 || (db == d0 && k < i0), lt1 = db < d1 || (db == d1 && k < i1);
@@ -296,6 +295,28 @@ __global__ __launch_bounds__(kNnTileThreads) void three_nn_tile_kernel(int n, in
             d1 = lt0 ? d0 : (lt1 ? db : d1);  i1 = lt0 ? i0 : (lt1 ? k : i1);
             d0 = lt0 ? db : d0;               i0 = lt0 ? k : i0;
         }
+    };
+    auto offer4 = [&](const float4 p0, const float4 p1, const float4 p2, const float4 p3) {
+        const f2 ax = {p0.x, p1.x}, ay = {p0.y, p1.y}, az = {p0.z, p1.z};
+        const f2 bx = {p2.x, p3.x}, by = {p2.y, p3.y}, bz = {p2.z, p3.z};
+        const f2 adx = ux2 - ax, ady = uy2 - ay, adz = uz2 - az;
+        const f2 bdx = ux2 - bx, bdy = uy2 - by, bdz = uz2 - bz;
+        const f2 da = adx * adx + ady * ady + adz * adz;
+        const f2 dbv = bdx * bdx + bdy * bdy + bdz * bdz;
+        const int k0 = __float_as_int(p0.w), k1 = __float_as_int(p1.w), k2 = __float_as_int(p2.w), k3 = __float_as_int(p3.w);
+        // padding rows and non-finite distances never enter a list, as in the reference (interpolate_gpu.cu:37-48)
+        const float inf = __builtin_huge_valf();
+        const unsigned b0 = (k0 >= 0 && da.x < inf) ? __float_as_uint(da.x) : kNone;
+        const unsigned b1 = (k1 >= 0 && da.y < inf) ? __float_as_uint(da.y) : kNone;
+        const unsigned b2 = (k2 >= 0 && dbv.x < inf) ? __float_as_uint(dbv.x) : kNone;
+        const unsigned b3 = (k3 >= 0 && dbv.y < inf) ? __float_as_uint(dbv.y) : kNone;
+        // (ties with the third entry are rare: a conservative '<=' on the distance alone keeps the vote cheap)
+        const unsigned nearest = min(min(b0, b1), min(b2, b3));
+        if (!__ballot(nearest <= d2 && nearest != kNone)) return;
+        insert(b0, k0);
+        insert(b1, k1);
+        insert(b2, k2);
+        insert(b3, k3);
     };
     // A known bucket covers a 4x larger region than a bucket of unknowns (the known set is the 4x sparser FPS subset), so most of
     // its 64 points are out of reach even when the bucket's box is not: the box of each ROW of 16 consecutive points (compact:
@@ -326,10 +347,7 @@ __global__ __launch_bounds__(kNnTileThreads) void three_nn_tile_kernel(int n, in
 #pragma unroll
             for (int j = r * 16; j < r * 16 + 16; j += 4) {
                 const float4 p0 = pts[j], p1 = pts[j + 1], p2 = pts[j + 2], p3 = pts[j + 3];
-                offer(p0);
-                offer(p1);
-                offer(p2);
-                offer(p3);
+                offer4(p0, p1, p2, p3);
             }
         }
     };
