@@ -4,13 +4,17 @@
 #   2. rocprofv3 --kernel-trace --stats of the UNOVERLAPPED run (`--pipelined 0 --no-overlap --no-graph`: every kernel
 #      alone on the device, the execution bench.py's per-kernel HIP-event numbers come from) + per-family table
 #   3. two PMC passes (FETCH_SIZE, WRITE_SIZE; --kernel-trace only) of the unoverlapped run + per-family HBM bytes
-# usage: bash profiles/collect.sh TAG      -> gpurun_out/prof_TAG/*  (copy what should be judged into profiles/)
+#   4. per-op timings, the step with the FP ops, the batch sweep, BASELINE config 5, the training steps of configs 3 / 4
+# usage: bash profiles/collect.sh TAG [a|b|c]  -> gpurun_out/prof_TAG/*  (copy what should be judged into profiles/)
+#        (three parts, each within one gpurun call's time limit: a = 1-3, b = per-op / FP / sweep / config 5, c = training steps)
 set -e
 TAG=${1:-r02}
+PART=${2:-abc}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
-rm -rf $OUT && mkdir -p $OUT
+mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
+if [[ $PART == *a* ]]; then
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 echo "bench done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_default -- python3 bench.py --cpu-scenes 0 --extras "" --verify-scenes 0 > $OUT/bench_under_rocprof.json
@@ -30,6 +34,8 @@ BATCH=$(python3 -c "import json;print(json.load(open('$OUT/bench.json'))['config
 python3 profiles/summarize.py pmc $F $W $BATCH $OUT/pmc_traffic.json
 cp $F $OUT/pmc_fetch_size.csv; cp $W $OUT/pmc_write_size.csv
 rm -rf $OUT/stats_default $OUT/stats_alone $OUT/pmc_fetch $OUT/pmc_write
+fi
+if [[ $PART == *b* ]]; then
 python3 bench_ops.py > $OUT/bench_ops.jsonl
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_ops -- python3 bench_ops.py --reps 5 > $OUT/bench_ops_under_rocprof.jsonl
 cp $(find $OUT/stats_ops -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_ops.csv
@@ -45,6 +51,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_cfg5 -- pytho
 cp $(find $OUT/stats_cfg5 -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_config5_alone.csv
 rm -rf $OUT/stats_cfg5
 echo "config 5 done"
+fi
+if [[ $PART == *c* ]]; then
 # configs 3 / 4 (per-rank part): the training steps around the hot path, the point stream alone for comparison
 python3 bench_step.py > $OUT/bench_step_points.json
 python3 bench_step.py --image --rpn-only > $OUT/bench_step_config3.json
@@ -55,3 +63,4 @@ cp $(find $OUT/stats_step -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats
 rm -rf $OUT/stats_step
 for B in 1 2; do python3 bench_step.py --infer --batch $B --steps 30 >> $OUT/bench_step_infer.jsonl; done
 echo "training-step passes done"
+fi
