@@ -125,11 +125,14 @@ class SAStack:
         self.fp_bufs = []
         if with_fp:
             for c, m, nn_ in fp:
+                sets = [{"dist2": torch.empty((batch, nn_, 3), dtype=f32, device=dev),
+                         "idx": torch.empty((batch, nn_, 3), dtype=i32, device=dev),
+                         "weight": torch.empty((batch, nn_, 3), dtype=f32, device=dev)} for _ in range(2 if pipelined else 1)]
                 self.fp_bufs.append({
                     "c": c, "m": m, "n": nn_,
                     "known_feats": torch.randn((batch, c, m), generator=g, dtype=f32).to(dev),
-                    "dist2": torch.empty((batch, nn_, 3), dtype=f32, device=dev),
-                    "idx": torch.empty((batch, nn_, 3), dtype=i32, device=dev),
+                    "sets": sets,                       # what the interpolation (stage G) reads from the neighbour search
+                    "dist2": sets[0]["dist2"], "idx": sets[0]["idx"],   # (the last written set: see _search_fp)
                     "out": torch.empty((batch, c, nn_), dtype=f32, device=dev),
                 })
         self.graphs = []
@@ -263,33 +266,49 @@ class SAStack:
                     self._query_scale(first, S, prev_xyz, 1 - parity)
                     self._group_scale(first, S, prev_xyz, 1 - parity)
             if self.with_fp:
-                self._run_fp(prev_xyz, 1 - parity)
+                self._interpolate_fp(1 - parity)
         cur = xyz
         for L in self.levels:
             cur = self._sample_level(L, cur, parity, index_built=L is first)
+        if self.with_fp:
+            self._search_fp(xyz, parity)
         # if the sampling chain is the shorter stage it can take level-1 scales of stage G as its tail
         for S in first["scales"][:self.tail_scales]:
             self._query_scale(first, S, prev_xyz, 1 - parity)
             self._group_scale(first, S, prev_xyz, 1 - parity)
         main.wait_stream(side)
 
-    def _run_fp(self, xyz, parity):
+    def _search_fp(self, xyz, parity):
+        """three_nn + the interpolation weights of every FP level for the batch whose centres / indices are in set `parity`.
+        The search is arithmetic-bound and needs nothing but coordinates, so the pipelined schedule runs it at the tail of
+        stage S (the latency-bound chain leaves the chip's issue slots idle) instead of in front of the interpolation in stage G"""
         b = self.batch
         # FP modules walk back up: unknown = xyz of the finer level, known = the coarser one
         xyzs = [xyz] + [L["sets"][parity]["new_xyz"] for L in self.levels]
         # the scene index of level l's INPUT points is sets[parity]["index"] of level l
         indices = [L["sets"][parity]["index"] for L in self.levels] + [None]
         for k, F in enumerate(self.fp_bufs):
+            P = F["sets"][parity if len(F["sets"]) > 1 else 0]
             known = xyzs[len(self.levels) - k]
             unknown = xyzs[len(self.levels) - k - 1]
             k_index, u_index = indices[len(self.levels) - k], indices[len(self.levels) - k - 1]
             if k_index is not None:
-                ext.three_nn_indexed_wrapper(b, F["n"], F["m"], unknown, known, u_index, k_index, F["dist2"], F["idx"])
+                ext.three_nn_indexed_wrapper(b, F["n"], F["m"], unknown, known, u_index, k_index, P["dist2"], P["idx"])
             else:
-                ext.three_nn_wrapper(b, F["n"], F["m"], unknown, known, F["dist2"], F["idx"])
-            inv = 1.0 / (torch.sqrt(F["dist2"]) + 1e-8)      # pointnet2_modules.py:157-159
-            weight = inv / torch.sum(inv, dim=2, keepdim=True)
-            ext.three_interpolate_wrapper(b, F["c"], F["m"], F["n"], F["known_feats"], F["idx"], weight, F["out"])
+                ext.three_nn_wrapper(b, F["n"], F["m"], unknown, known, P["dist2"], P["idx"])
+            inv = 1.0 / (torch.sqrt(P["dist2"]) + 1e-8)      # pointnet2_modules.py:157-159
+            torch.div(inv, torch.sum(inv, dim=2, keepdim=True), out=P["weight"])
+            F["dist2"], F["idx"] = P["dist2"], P["idx"]
+
+    def _interpolate_fp(self, parity):
+        b = self.batch
+        for F in self.fp_bufs:
+            P = F["sets"][parity if len(F["sets"]) > 1 else 0]
+            ext.three_interpolate_wrapper(b, F["c"], F["m"], F["n"], F["known_feats"], P["idx"], P["weight"], F["out"])
+
+    def _run_fp(self, xyz, parity):
+        self._search_fp(xyz, parity)
+        self._interpolate_fp(parity)
 
     def _prime(self, xyz):
         """before the first pipelined step: stage S of `xyz` into BOTH sets, so that the first steps' stage G (the
@@ -298,6 +317,8 @@ class SAStack:
             cur = xyz
             for L in self.levels:
                 cur = self._sample_level(L, cur, parity)
+            if self.with_fp:
+                self._search_fp(xyz, parity)
 
     def _step_eager(self, k):
         if self.pipelined:
