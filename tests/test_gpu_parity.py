@@ -1062,8 +1062,11 @@ def test_the_benchs_own_configuration_against_the_oracle(oracle, with_fp, kind):
         for S in L["scales"]:
             S["idx"].zero_()
             S["grouped"].fill_(float("nan"))
-    for F in stack.fp_bufs:
-        F["idx"].fill_(-1); F["dist2"].fill_(float("nan")); F["out"].fill_(float("nan"))
+    for F in stack.fp_bufs:   # (the neighbour indices are read by the NEXT step's interpolation: they stay valid indices)
+        F["out"].fill_(float("nan"))
+        for P in F["sets"]:
+            P["idx"].zero_()
+            P["dist2"].fill_(float("nan"))
     for _ in range(3):            # both graphs of the rotation; the third replay regroups what the second one sampled
         stack.replay()
     torch.cuda.synchronize()
