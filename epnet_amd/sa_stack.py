@@ -73,7 +73,7 @@ def fp_algorithmic_bytes(fp=RPN_FP):
 class SAStack:
     def __init__(self, batch, n=16384, device="cuda", npoints=RPN_NPOINTS, radii=RPN_RADII, nsamples=RPN_NSAMPLES,
                  feat_channels=RPN_FEAT_CHANNELS, with_fp=False, fp=RPN_FP, seed=0, overlap=True, fused=True,
-                 shared_index=True, pipelined=False, fused_sampling=False):
+                 shared_index=True, pipelined=False, fused_sampling=False, queries_in_s=None):
         self.batch, self.n = batch, n
         # overlap: FPS/gather of level l+1 depend only on the centres of level l (never on features), so
         # the sampling chain runs ahead on the launch stream while ball query + grouping of each level
@@ -85,6 +85,12 @@ class SAStack:
         # epnet_sample_centres (FPS + row gather of the centres: 3 launches per level with the index build) instead of the
         # reference module's op-by-op sequence (transpose, fill, FPS, gather, transpose: 6 launches): 256-scene step 3.78 -> 3.66 ms
         self.fused_sampling = fused_sampling
+        # With the FP ops in the step stage G carries 2.2 ms of interpolation on top of the groupings: the ball queries (latency /
+        # issue bound, 0.57 ms) then move to the tail of stage S as well, behind the sampling and the neighbour search of the same
+        # batch, and hand their index tensors to the next step's grouping (double-buffered). 256-scene step with FP ops:
+        # 7.17 (everything in G) -> 6.60 (three_nn in S) -> see DESIGN.md section 5
+        self.queries_in_s = (bool(int(os.environ.get("EPNET_SA_QUERIES_IN_S", "1"))) and with_fp and pipelined) if queries_in_s is None \
+            else bool(queries_in_s and pipelined)
         self.tail_scales = int(os.environ.get("EPNET_SA_TAIL_SCALES", "0"))
         self.multi_query = bool(int(os.environ.get("EPNET_SA_MULTI_QUERY", "1")))  # both scales of a level in one launch
         self.multi_group = bool(int(os.environ.get("EPNET_SA_MULTI_GROUP", "1")))  # both groupings of a level in one call
@@ -114,6 +120,7 @@ class SAStack:
             }
             for radius, ns in zip(radii[lvl], nsamples[lvl]):
                 S = {"radius": radius, "ns": ns, "idx": torch.empty((batch, m, ns), dtype=i32, device=dev)}
+                S["idx_sets"] = [S["idx"]] + ([torch.empty((batch, m, ns), dtype=i32, device=dev)] if self.queries_in_s else [])
                 if fused:
                     S["grouped"] = torch.empty((batch, 3 + c, m, ns), dtype=f32, device=dev)
                 else:
@@ -162,24 +169,28 @@ class SAStack:
             P["new_xyz"].copy_(L["new_xyz_t"].transpose(1, 2))    # pointnet2_modules.py:42-45
         return P["new_xyz"]
 
+    def _idx(self, S, parity):
+        """the neighbour-index tensor of a scale: one per pipeline parity when the queries run in stage S"""
+        return S["idx_sets"][parity] if len(S["idx_sets"]) > 1 else S["idx"]
+
     # ---- stage G: neighbour search + grouping of one level
     def _query_scale(self, L, S, cur_xyz, parity):
         b, n, m = self.batch, L["n"], L["m"]
         P = L["sets"][parity]
         if P["index"] is not None:
-            ext.ball_query_indexed_wrapper(b, n, m, S["radius"], S["ns"], P["new_xyz"], cur_xyz, P["index"], S["idx"])
+            ext.ball_query_indexed_wrapper(b, n, m, S["radius"], S["ns"], P["new_xyz"], cur_xyz, P["index"], self._idx(S, parity))
         else:
-            ext.ball_query_wrapper(b, n, m, S["radius"], S["ns"], P["new_xyz"], cur_xyz, S["idx"])
+            ext.ball_query_wrapper(b, n, m, S["radius"], S["ns"], P["new_xyz"], cur_xyz, self._idx(S, parity))
 
     def _group_scale(self, L, S, cur_xyz, parity):
         b, n, m = self.batch, L["n"], L["m"]
         if self.fused:   # pointnet2_utils.py:249-257 in one call
             ext.group_concat_wrapper(b, L["c"], n, m, S["ns"], cur_xyz, L["sets"][parity]["new_xyz"], L["features"],
-                                     S["idx"], S["grouped"], True)
+                                     self._idx(S, parity), S["grouped"], True)
         else:
-            ext.group_points_wrapper(b, 3, n, m, S["ns"], L["xyz_t"], S["idx"], S["grouped_xyz"])
+            ext.group_points_wrapper(b, 3, n, m, S["ns"], L["xyz_t"], self._idx(S, parity), S["grouped_xyz"])
             if L["c"]:
-                ext.group_points_wrapper(b, L["c"], n, m, S["ns"], L["features"], S["idx"], S["grouped_feat"])
+                ext.group_points_wrapper(b, L["c"], n, m, S["ns"], L["features"], self._idx(S, parity), S["grouped_feat"])
 
     def _query_level(self, L, cur_xyz, parity):
         """the ball queries of all scales of the level: one launch over the shared index"""
@@ -187,7 +198,7 @@ class SAStack:
         if P["index"] is not None and self.multi_query:
             ext.ball_query_multi_wrapper(self.batch, L["n"], L["m"], [S["radius"] for S in L["scales"]],
                                          [S["ns"] for S in L["scales"]], P["new_xyz"], cur_xyz, P["index"],
-                                         [S["idx"] for S in L["scales"]])
+                                         [self._idx(S, parity) for S in L["scales"]])
         else:
             for S in L["scales"]:
                 self._query_scale(L, S, cur_xyz, parity)
@@ -196,7 +207,7 @@ class SAStack:
         """the groupings of all scales of the level: one call (feature rows staged once for both scales)"""
         if self.fused and self.multi_group and len(L["scales"]) > 1:
             ext.group_concat_multi_wrapper(self.batch, L["c"], L["n"], L["m"], [S["ns"] for S in L["scales"]], cur_xyz,
-                                           L["sets"][parity]["new_xyz"], L["features"], [S["idx"] for S in L["scales"]],
+                                           L["sets"][parity]["new_xyz"], L["features"], [self._idx(S, parity) for S in L["scales"]],
                                            [S["grouped"] for S in L["scales"]], True)
         else:
             for S in L["scales"]:
@@ -251,20 +262,24 @@ class SAStack:
             # for the first 2.5 ms of the step: the LDS-staged feature gathers of levels 2-4 (few registers) run
             # beside it, the level-1 ball queries (occupancy-hungry) after it.
             inputs = [prev_xyz] + [L["sets"][1 - parity]["new_xyz"] for L in self.levels[:-1]]
-            deep = list(zip(self.levels, inputs))[1:]
-            for k, (L, cur) in enumerate(deep):
-                if k == 0:       # level 2 (indexed queries: few registers) then its gathers beside the level-1 FPS
-                    self._group_level(L, cur, 1 - parity)
-            for L, cur in deep[1:]:
-                self._query_level(L, cur, 1 - parity)
-            for L, cur in deep[1:]:
-                self._group_scales(L, cur, 1 - parity)
-            if self.tail_scales == 0:
-                self._group_level(first, prev_xyz, 1 - parity)
+            if self.queries_in_s:   # the index tensors of the previous batch are ready: stage G is the groupings alone
+                for L, cur in list(zip(self.levels, inputs))[1:] + [(first, prev_xyz)]:
+                    self._group_scales(L, cur, 1 - parity)
             else:
-                for S in first["scales"][self.tail_scales:]:
-                    self._query_scale(first, S, prev_xyz, 1 - parity)
-                    self._group_scale(first, S, prev_xyz, 1 - parity)
+                deep = list(zip(self.levels, inputs))[1:]
+                for k, (L, cur) in enumerate(deep):
+                    if k == 0:       # level 2 (indexed queries: few registers) then its gathers beside the level-1 FPS
+                        self._group_level(L, cur, 1 - parity)
+                for L, cur in deep[1:]:
+                    self._query_level(L, cur, 1 - parity)
+                for L, cur in deep[1:]:
+                    self._group_scales(L, cur, 1 - parity)
+                if self.tail_scales == 0:
+                    self._group_level(first, prev_xyz, 1 - parity)
+                else:
+                    for S in first["scales"][self.tail_scales:]:
+                        self._query_scale(first, S, prev_xyz, 1 - parity)
+                        self._group_scale(first, S, prev_xyz, 1 - parity)
             if self.with_fp:
                 self._interpolate_fp(1 - parity)
         cur = xyz
@@ -272,11 +287,20 @@ class SAStack:
             cur = self._sample_level(L, cur, parity, index_built=L is first)
         if self.with_fp:
             self._search_fp(xyz, parity)
+        if self.queries_in_s:
+            self._queries_of(xyz, parity)
         # if the sampling chain is the shorter stage it can take level-1 scales of stage G as its tail
-        for S in first["scales"][:self.tail_scales]:
+        for S in first["scales"][:(0 if self.queries_in_s else self.tail_scales)]:
             self._query_scale(first, S, prev_xyz, 1 - parity)
             self._group_scale(first, S, prev_xyz, 1 - parity)
         main.wait_stream(side)
+
+    def _queries_of(self, xyz, parity):
+        """the ball queries of every level for the batch whose centres / indices are in set `parity`"""
+        cur = xyz
+        for L in self.levels:
+            self._query_level(L, cur, parity)
+            cur = L["sets"][parity]["new_xyz"]
 
     def _search_fp(self, xyz, parity):
         """three_nn + the interpolation weights of every FP level for the batch whose centres / indices are in set `parity`.
@@ -319,6 +343,8 @@ class SAStack:
                 cur = self._sample_level(L, cur, parity)
             if self.with_fp:
                 self._search_fp(xyz, parity)
+            if self.queries_in_s:
+                self._queries_of(xyz, parity)
 
     def _step_eager(self, k):
         if self.pipelined:
