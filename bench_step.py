@@ -281,25 +281,25 @@ def main():
     # ---- share of the step spent inside this package's operators: an instrumented pass with a HIP event pair around every
     # call into the three extension stand-ins (on the stream the call launches on), against the GPU time of the same steps
     ops_share = None
+    import contextlib
+    import bench
+    from epnet_amd import iou3d_cuda, pointnet2_cuda, roipool3d_cuda
+    iou_names = [n for n in ("boxes_overlap_bev_gpu", "boxes_iou_bev_gpu", "boxes_iou3d_fused_gpu", "boxes_iou3d_pairs_gpu",
+                             "aug_roi_by_noise_gpu", "rpn_proposals_gpu", "nms_device", "nms_normal_device")]
+    timers = ([bench.OpTimer(torch, pointnet2_cuda), bench.OpTimer(torch, iou3d_cuda, iou_names),
+               bench.OpTimer(torch, roipool3d_cuda, ["forward"])] if rank == 0 else [])
+    reps = max(2, min(5, args.steps))
+    with contextlib.ExitStack() as stack:       # (every rank takes the steps: the gradient all-reduce needs all of them)
+        for t in timers:
+            stack.enter_context(t)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            one(False)
+        e1.record()
+        torch.cuda.synchronize()
     if rank == 0:
-        import contextlib
-        import bench
-        from epnet_amd import iou3d_cuda, pointnet2_cuda, roipool3d_cuda
-        iou_names = [n for n in ("boxes_overlap_bev_gpu", "boxes_iou_bev_gpu", "boxes_iou3d_fused_gpu", "boxes_iou3d_pairs_gpu",
-                                 "aug_roi_by_noise_gpu", "rpn_proposals_gpu", "nms_device", "nms_normal_device")]
-        timers = [bench.OpTimer(torch, pointnet2_cuda), bench.OpTimer(torch, iou3d_cuda, iou_names),
-                  bench.OpTimer(torch, roipool3d_cuda, ["forward"])]
-        reps = max(2, min(5, args.steps))
-        with contextlib.ExitStack() as stack:
-            for t in timers:
-                stack.enter_context(t)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize()
-            e0.record()
-            for _ in range(reps):
-                one(False)
-            e1.record()
-            torch.cuda.synchronize()
         per_op = {}
         for t in timers:
             for name, _head, a, b_ in t.records:
