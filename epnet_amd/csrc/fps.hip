@@ -112,7 +112,9 @@ __device__ __forceinline__ void find_slot(const int (&t)[PPT], const float (&x)[
 // R = bs / (64*W), J = ceil(n / bs), R*J <= PPT.
 template <int W, int PPT>
 __global__ __launch_bounds__(64 * W) void fps_wave_kernel(int n, int m, int lg_bs, const float *__restrict__ xyz,
-                                                          float *__restrict__ temp, int *__restrict__ idxs) {
+                                                          float *__restrict__ temp, int *__restrict__ idxs,
+                                                          const int *__restrict__ skip) {
+    if (skip && skip[blockIdx.x] >= m) return;  // this scene's first m points are the samples already (fps_prefix_kernel)
     __shared__ int s_val[2][16];     // per-wave maximum (bit pattern)
     __shared__ float4 s_rec[2][16];  // per-wave candidate: x, y, z, (q << 8 | slot) as int bits
     __shared__ int s_idx[kIdxBuf];
@@ -364,7 +366,7 @@ __device__ __forceinline__ void set_rank(VH &rk2, int j, unsigned r) {  // j is 
 template <int kW, int PPT, bool kCtr, typename VF, typename VI, typename VH>
 __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, const VF &z, VI &t, const VH &rk2,
                                            float cx, float cy, float cz, int *__restrict__ idxs,
-                                           float *__restrict__ ctr) {
+                                           float *__restrict__ ctr, int *__restrict__ tie_free = nullptr) {
     __shared__ unsigned long long s_key[3];
     __shared__ float4 s_rec[2][64 * kW];  // one record slot per thread
     __shared__ int s_idx[kIdxBufP];
@@ -410,6 +412,10 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
     unsigned racc = 0xFFFFFFFFu;  // != ~0 in the lanes that publish
     float xa = 0.f, ya = 0.f, za = 0.f;
     int kb = 1;  // key slot of the round = it % 3
+    // the first round whose maximum is NOT unique (several points at the maximum running distance: the reference's tie-break
+    // decides): up to that round the sequence of samples is a property of the coordinates alone (see epnet_sample_centres_chain)
+    bool wave_multi = false;  // several points of this wave hold its maximum
+    int tied_at = m;
     for (int it = 1; it < m; ++it) {
         EPNET_STAMP(t0);
         // A. which buckets can change?
@@ -447,6 +453,7 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
             unsigned cand = fold_parts<PPT>(__ballot(bm == wbest));
             racc = 0xFFFFFFFFu;
             hbuckets = 0ull;
+            int held = 0;  // points of this lane at the wave's maximum
             do {
                 const int j = (int)__builtin_ctz(cand);
                 cand &= cand - 1u;
@@ -456,12 +463,17 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
                 __builtin_amdgcn_sched_barrier(0);  // one GPR-index window for the four slot registers
                 const unsigned r = tj == wbest ? ((rw >> ((j & 1) << 4)) & 0xFFFFu) : 0xFFFFFFFFu;
                 if (r != 0xFFFFFFFFu) hbuckets |= 1ull << ((lane & ~(PPT - 1)) | j);  // summary lane of (slot j, my part)
+                held += r != 0xFFFFFFFFu ? 1 : 0;
                 const bool take = r < racc;  // a lane holding the maximum in two of its slots keeps the smaller rank
                 racc = take ? r : racc;
                 xa = take ? xj : xa;
                 ya = take ? yj : ya;
                 za = take ? zj : za;
             } while (cand);
+            if (tie_free) {
+                const unsigned long long holders = __ballot(held > 0);
+                wave_multi = (holders & (holders - 1ull)) != 0ull || __ballot(held > 1) != 0ull;
+            }
             if (wbest == kNeg1) {  // a wave of padding only
                 racc = 0xFFFFFFFFu;
                 hbuckets = 0ull;
@@ -478,11 +490,17 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
         __syncthreads();
         EPNET_STAMP(t4);
         // D. the winner: key, then its thread's coordinates (both loads are wave-uniform broadcasts)
-        const unsigned klo = (unsigned)s_key[kb];
+        const unsigned long long kfull = s_key[kb];
+        const unsigned klo = (unsigned)kfull;
         const float4 rec = s_rec[buf][klo & 1023u];
         cx = rec.x;
         cy = rec.y;
         cz = rec.z;
+        if (tie_free && tied_at == m) {
+            // this wave's (exact, possibly cached) maximum equals the winner's distance: a tie unless it IS the winner alone
+            const bool mine = (int)((klo & 1023u) >> 6) == wave;
+            if (wbest == (int)(unsigned)(kfull >> 32) && (!mine || wave_multi)) tied_at = it;
+        }
         const int kb2 = kb == 0 ? 2 : kb - 1;  // == (it + 2) % 3: last read in round it-1, next used in round it+2
         kb = kb == 2 ? 0 : kb + 1;
         if (wave == 0) {
@@ -504,6 +522,7 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
     EPNET_STAMP(t_loop1);
     EPNET_ACC(6, t_loop0, t_loop1);
     EPNET_STATS_END;
+    if (tie_free && lane == 0) atomicMin(tie_free, tied_at);  // (initialised to m by the caller's launch sequence)
     if (wave == 0) {
         const int base = (m - 1) & ~(kIdxBufP - 1);
         for (int e = lane; base + e < m; e += 64) idxs[base + e] = unrank14((unsigned)s_idx[e]);
@@ -517,7 +536,9 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
 // Self-contained kernel (no caller scratch): counting-sorts the scene by grid cell in LDS, then runs the rounds.
 template <int kW, int PPT>
 __global__ __launch_bounds__(64 * kW) void fps_pruned_kernel(int n, int m, const float *__restrict__ xyz,
-                                                             float *__restrict__ temp, int *__restrict__ idxs) {
+                                                             float *__restrict__ temp, int *__restrict__ idxs,
+                                                             const int *__restrict__ skip, int *__restrict__ prefix_out) {
+    if (skip && skip[blockIdx.x] >= m) return;
     typedef float vecf __attribute__((ext_vector_type(PPT)));
     typedef int veci __attribute__((ext_vector_type(PPT)));
     constexpr int kT = 64 * kW;
@@ -564,7 +585,8 @@ __global__ __launch_bounds__(64 * kW) void fps_pruned_kernel(int n, int m, const
             set_rank(rk2, j, 0xFFFFu);
         }
     }
-    fps_rounds<kW, PPT, false>(m, x, y, z, t, rk2, xyz[0], xyz[1], xyz[2], idxs, nullptr);
+    fps_rounds<kW, PPT, false>(m, x, y, z, t, rk2, xyz[0], xyz[1], xyz[2], idxs, nullptr,
+                               prefix_out ? prefix_out + blockIdx.x : nullptr);
     if (temp) {
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
@@ -579,13 +601,15 @@ __global__ __launch_bounds__(64 * kW) void fps_pruned_kernel(int n, int m, const
 template <int kW, int PPT, bool kCtr>
 __global__ __launch_bounds__(64 * kW) void fps_indexed_kernel(int n, int m, const float4 *__restrict__ sorted,
                                                               float *__restrict__ temp, int *__restrict__ idxs,
-                                                              float *__restrict__ ctr) {
+                                                              float *__restrict__ ctr, const int *__restrict__ prefix_in,
+                                                              int *__restrict__ prefix_out) {
     typedef float vecf __attribute__((ext_vector_type(PPT)));
     typedef int veci __attribute__((ext_vector_type(PPT)));
     constexpr int NP = 64 * kW * PPT;
     __shared__ float s_first[4];
     const int q = threadIdx.x;
     const int lane = q & 63, wave = q >> 6;
+    if (prefix_in && prefix_in[blockIdx.x] >= m) return;  // the first m points ARE the samples (fps_prefix_kernel wrote them)
     sorted += (size_t)blockIdx.x * NP;
     if (temp) temp += (size_t)blockIdx.x * n;
     idxs += (size_t)blockIdx.x * m;
@@ -616,7 +640,8 @@ __global__ __launch_bounds__(64 * kW) void fps_indexed_kernel(int n, int m, cons
         }
     }
     __syncthreads();
-    fps_rounds<kW, PPT, kCtr>(m, x, y, z, t, rk2, s_first[0], s_first[1], s_first[2], idxs, ctr);
+    fps_rounds<kW, PPT, kCtr>(m, x, y, z, t, rk2, s_first[0], s_first[1], s_first[2], idxs, ctr,
+                              prefix_out ? prefix_out + blockIdx.x : nullptr);
     if (temp) {
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
@@ -646,7 +671,8 @@ __global__ __launch_bounds__(kBigThreads) void fps_bigscene_kernel(int n, int np
                                                                   const float4 *__restrict__ sorted,
                                                                   const float *__restrict__ boxes,
                                                                   float *__restrict__ temp, float *__restrict__ tsort,
-                                                                  int *__restrict__ idxs) {
+                                                                  int *__restrict__ idxs, const int *__restrict__ skip) {
+    if (skip && skip[blockIdx.x] >= m) return;
     __shared__ unsigned long long s_key[3];
     __shared__ float4 s_rec[2][16];
     __shared__ int s_idx[kIdxBufP];
@@ -853,7 +879,9 @@ __device__ __forceinline__ long long wave_max_i64(long long v) {
 // (bits(d2) << 32) | (0x7fffffff - rank(k)), whose unique maximum is the reference's winner.
 // blockDim.x is a multiple of the reference block size 2^lg_bs, so a thread's points share k mod bs.
 __global__ __launch_bounds__(1024) void fps_stream_kernel(int n, int m, int lg_bs, const float *__restrict__ xyz,
-                                                          float *__restrict__ temp, int *__restrict__ idxs) {
+                                                          float *__restrict__ temp, int *__restrict__ idxs,
+                                                          const int *__restrict__ skip) {
+    if (skip && skip[blockIdx.x] >= m) return;
     __shared__ long long red[2][16];
     const int BS = blockDim.x;
     const int q = threadIdx.x;
@@ -910,8 +938,11 @@ static int ref_block_lg(int work_size) {
 
 using namespace epnet;
 
-extern "C" int epnet_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp, int *idx,
-                                             epnet_stream_t stream) {
+// skip: per scene, "the first skip[b] points of xyz are an unambiguous furthest-point sequence" (scenes with skip[b] >= m are
+// left alone: fps_prefix_kernel has written their samples); prefix_out: per scene, receives the number of leading rounds of
+// THIS sampling whose maximum was unique (initialised by fps_prefix_kernel) where the kernel can tell. Both may be NULL.
+static int fps_plain(int b, int n, int m, const float *xyz, float *temp, int *idx, const int *skip, int *prefix_out,
+                     epnet_stream_t stream) {
     EPNET_REQUIRE(b >= 0 && n >= 1 && m >= 0);
     if (b == 0 || m == 0) return EPNET_OK;  // the reference kernel returns at once for m <= 0
     EPNET_REQUIRE(xyz && idx);
@@ -936,7 +967,7 @@ extern "C" int epnet_furthest_point_sampling(int b, int n, int m, const float *x
         const int ppt = ppt_need <= 8 ? 8 : ppt_need <= 16 ? 16 : 32;
         const size_t lds = (size_t)(kCells + kCells / (kCells / (64 * waves)) + 64) * sizeof(int) + (size_t)64 * waves * ppt * 2;
 #define EPNET_FPS_PRUNED(W_, P_) \
-    hipLaunchKernelGGL((pruned::fps_pruned_kernel<W_, P_>), grid, dim3(64 * W_), lds, s, n, m, xyz, temp, idx)
+    hipLaunchKernelGGL((pruned::fps_pruned_kernel<W_, P_>), grid, dim3(64 * W_), lds, s, n, m, xyz, temp, idx, skip, prefix_out)
         if (waves == 8) {
             if (ppt == 8) EPNET_FPS_PRUNED(8, 8);
             else if (ppt == 16) EPNET_FPS_PRUNED(8, 16);
@@ -971,7 +1002,7 @@ extern "C" int epnet_furthest_point_sampling(int b, int n, int m, const float *x
         }
         const int ppt = (bs_ref / (64 * waves)) * J;
 #define EPNET_FPS_LAUNCH(W_, P_) \
-    hipLaunchKernelGGL((fps_wave_kernel<W_, P_>), grid, dim3(64 * W_), 0, s, n, m, lg, xyz, temp, idx)
+    hipLaunchKernelGGL((fps_wave_kernel<W_, P_>), grid, dim3(64 * W_), 0, s, n, m, lg, xyz, temp, idx, skip)
 #define EPNET_FPS_PPT(W_)                      \
     do {                                       \
         if (ppt <= 1) EPNET_FPS_LAUNCH(W_, 1); \
@@ -995,8 +1026,33 @@ extern "C" int epnet_furthest_point_sampling(int b, int n, int m, const float *x
     float *tbuf = temp;
     if (!tbuf) return EPNET_EINVAL;  // temp may only be NULL on the register-resident path
     const int bs = bs_ref < 64 ? 64 : bs_ref;
-    hipLaunchKernelGGL(fps_stream_kernel, grid, dim3(bs), 0, s, n, m, lg, xyz, tbuf, idx);
+    hipLaunchKernelGGL(fps_stream_kernel, grid, dim3(bs), 0, s, n, m, lg, xyz, tbuf, idx, skip);
     return check_launch("furthest_point_sampling");
+}
+
+extern "C" int epnet_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp, int *idx,
+                                             epnet_stream_t stream) {
+    return fps_plain(b, n, m, xyz, temp, idx, nullptr, nullptr, stream);
+}
+
+// does the kernel the dispatch above / below picks report its tie-free rounds? (the pruned kernels do)
+static bool fps_detects_ties(int n, int m, bool indexed) {
+    if (m <= 1 || n <= 1024 || n > 16384) return false;
+    if (indexed) return true;
+    const bool prune_enabled = !(getenv("EPNET_FPS_PRUNE") && atoi(getenv("EPNET_FPS_PRUNE")) == 0);
+    const int prune_min = getenv("EPNET_FPS_PRUNE_MIN") ? atoi(getenv("EPNET_FPS_PRUNE_MIN")) : 1024;
+    return prune_enabled && n > prune_min;
+}
+
+// scenes whose first m points are known to be the samples (skip[b] >= m): idx = 0 .. m-1, and the knowledge is passed on;
+// the others: prefix_out starts at `init` (m where the sampling kernel reports ties by lowering it, 0 where it cannot tell)
+__global__ __launch_bounds__(256) void fps_prefix_kernel(int m, const int *__restrict__ skip, int *__restrict__ idx,
+                                                         int *__restrict__ prefix_out, int init) {
+    const int bs = blockIdx.x;
+    const bool known = skip && skip[bs] >= m;
+    if (threadIdx.x == 0 && prefix_out) prefix_out[bs] = known ? skip[bs] : init;
+    if (!known) return;
+    for (int i = threadIdx.x; i < m; i += 256) idx[(size_t)bs * m + i] = i;
 }
 
 // rows of the (B,N,3) cloud picked by idx (B,M): the centres of an SA level
@@ -1011,13 +1067,21 @@ __global__ __launch_bounds__(256) void gather_centres_kernel(int n, int m, const
 
 // shared by the two entry points below; new_xyz may be NULL
 static int fps_over_index(int b, int n, int m, const float *xyz, const void *index, size_t index_bytes, float *temp, int *idx,
-                          float *new_xyz, hipStream_t s) {
+                          float *new_xyz, hipStream_t s, const int *skip = nullptr, int *prefix_out = nullptr) {
     const size_t need = scene_index_bytes(b, n);
     bool centres_done = false;
     int rc;
+    const bool plain = need == 0 || !index || n <= 1024 || m <= 1 || (n > 16384 && !temp);
+    if (skip || prefix_out) {
+        EPNET_REQUIRE(idx && b <= 65535);
+        hipLaunchKernelGGL(fps_prefix_kernel, dim3(b), dim3(256), 0, s, m, skip, idx, prefix_out,
+                           fps_detects_ties(n, m, !plain) ? m : 0);
+        rc = check_launch("sampling prefix");
+        if (rc) return rc;
+    }
     // n <= 1024: the reference block size (hence the tie-break rank) depends on n; the one-wave kernel handles it
-    if (need == 0 || !index || n <= 1024 || m <= 1 || (n > 16384 && !temp)) {
-        rc = epnet_furthest_point_sampling(b, n, m, xyz, temp, idx, (epnet_stream_t)s);
+    if (plain) {
+        rc = fps_plain(b, n, m, xyz, temp, idx, skip, prefix_out, (epnet_stream_t)s);
     } else {
         EPNET_REQUIRE(idx);
         if (index_bytes < need) return EPNET_ENOMEM;
@@ -1027,21 +1091,21 @@ static int fps_over_index(int b, int n, int m, const float *xyz, const void *ind
             EPNET_REQUIRE(xyz);
             const int np = scene_index_np(n);
             hipLaunchKernelGGL(pruned::fps_bigscene_kernel, grid, dim3(pruned::kBigThreads), 0, s, n, np, m, xyz, sorted,
-                               (const float *)(sorted + (size_t)b * np), temp, scene_index_sampling_scratch(b, n, index), idx);
+                               (const float *)(sorted + (size_t)b * np), temp, scene_index_sampling_scratch(b, n, index), idx, skip);
         } else {
             const int wide = getenv("EPNET_FPS_WIDE") ? atoi(getenv("EPNET_FPS_WIDE")) : 0;
             // the centres can come out of the sampling kernel itself (kCtr: the round's winner is in registers anyway) or from a
             // small gather afterwards. In-kernel costs wave 0 an LDS write per round and 12 KB more LDS: 1.7 % on one scene,
             // 5 % in the software-pipelined stack -- more than the extra launch, so the separate gather is the default
-            const bool ctr_in_kernel = getenv("EPNET_FPS_CTR") && atoi(getenv("EPNET_FPS_CTR")) != 0;
+            const bool ctr_in_kernel = getenv("EPNET_FPS_CTR") && atoi(getenv("EPNET_FPS_CTR")) != 0 && !skip;
 #define EPNET_FPS_INDEXED(W_, P_)                                                                                          \
     do {                                                                                                                   \
         if (new_xyz && ctr_in_kernel)                                                                                      \
             hipLaunchKernelGGL((pruned::fps_indexed_kernel<W_, P_, true>), grid, dim3(64 * W_), 0, s, n, m, sorted, temp, \
-                               idx, new_xyz);                                                                              \
+                               idx, new_xyz, skip, prefix_out);                                                            \
         else                                                                                                               \
             hipLaunchKernelGGL((pruned::fps_indexed_kernel<W_, P_, false>), grid, dim3(64 * W_), 0, s, n, m, sorted, temp, \
-                               idx, (float *)nullptr);                                                                     \
+                               idx, (float *)nullptr, skip, prefix_out);                                                   \
     } while (0)
             switch (scene_index_np(n)) {
                 case 2048: EPNET_FPS_INDEXED(4, 8); break;
@@ -1080,4 +1144,21 @@ extern "C" int epnet_sample_centres(int b, int n, int m, const float *xyz, const
     if (b == 0 || m == 0) return EPNET_OK;
     EPNET_REQUIRE(xyz && idx && new_xyz);
     return fps_over_index(b, n, m, xyz, index, index_bytes, temp, idx, new_xyz, (hipStream_t)stream);
+}
+
+// epnet_sample_centres for the levels of a sampling PYRAMID (SA level l + 1 samples the centres of level l).
+// Furthest point sampling is nested: as long as every round's maximum is unique, the first m' samples of a sequence are the
+// furthest-point samples OF that sequence (the global maximiser over all points is itself one of the candidates; the running
+// distances are the same fp32 values), so idx = 0 .. m'-1 -- bit for bit what the reference's kernel computes on the centres,
+// whose tie-break only matters among equal maxima. prefix_in[b] (or NULL) = the number of leading rounds of the sampling that
+// produced xyz in which the maximum was unique; scenes with prefix_in[b] >= m take the identity, the others run the rounds.
+// prefix_out[b] (or NULL) receives the same knowledge about THIS sampling's output (0 where the kernel cannot tell).
+extern "C" int epnet_sample_centres_chain(int b, int n, int m, const float *xyz, const void *index, size_t index_bytes,
+                                          float *temp, int *idx, float *new_xyz, const int *prefix_in, int *prefix_out,
+                                          epnet_stream_t stream) {
+    EPNET_REQUIRE(b >= 0 && n >= 1 && m >= 0);
+    if (b == 0 || m == 0) return EPNET_OK;
+    EPNET_REQUIRE(xyz && idx && new_xyz);
+    if (m > n) prefix_in = nullptr;  // more samples than points: the sequence repeats points, nothing is known
+    return fps_over_index(b, n, m, xyz, index, index_bytes, temp, idx, new_xyz, (hipStream_t)stream, prefix_in, prefix_out);
 }

@@ -193,16 +193,28 @@ def furthest_point_sampling_indexed_wrapper(b, n, m, points, index, temp, idx):
     return 1
 
 
-@writes("idx", "new_xyz")
-def sample_centres_wrapper(b, n, m, points, index, idx, new_xyz):
-    """furthest_point_sampling from a fresh state + gather of the selected rows: idx (B,M) and new_xyz (B,M,3)"""
+@writes("idx", "new_xyz", "prefix_out")
+def sample_centres_wrapper(b, n, m, points, index, idx, new_xyz, prefix_in=None, prefix_out=None):
+    """furthest_point_sampling from a fresh state + gather of the selected rows: idx (B,M) and new_xyz (B,M,3).
+    prefix_in / prefix_out (int32 (B,) or None): the sampling pyramid's chain of knowledge (include/epnet_ops.h,
+    epnet_sample_centres_chain): scenes whose input is known to be an unambiguous furthest-point sequence of at least m
+    samples get idx = 0 .. m-1 without running the rounds -- the same result"""
     pp, pi, pn = dev_ptr(points, "points", _F), dev_ptr(idx, "idx", _I), dev_ptr(new_xyz, "new_xyz", _F)
     need(points, b * n * 3, "points"); need(idx, b * m, "idx"); need(new_xyz, b * m * 3, "new_xyz")
     px, nb = _index_args(index, points)
     temp = None if 64 <= n <= 16384 else torch.full((b, n), 1e10, dtype=_F, device=points.device)
+    pt = None if temp is None else temp.data_ptr()
     with on_device_of(points) as s:
-        _lib.check(_lib.lib().epnet_sample_centres(b, n, m, pp, px, nb, None if temp is None else temp.data_ptr(), pi, pn, s),
-                   "sample_centres")
+        if prefix_in is None and prefix_out is None:
+            _lib.check(_lib.lib().epnet_sample_centres(b, n, m, pp, px, nb, pt, pi, pn, s), "sample_centres")
+        else:
+            pin = dev_ptr(prefix_in, "prefix_in", _I) if prefix_in is not None else None
+            pout = dev_ptr(prefix_out, "prefix_out", _I) if prefix_out is not None else None
+            if prefix_in is not None:
+                need(prefix_in, b, "prefix_in")
+            if prefix_out is not None:
+                need(prefix_out, b, "prefix_out")
+            _lib.check(_lib.lib().epnet_sample_centres_chain(b, n, m, pp, px, nb, pt, pi, pn, pin, pout, s), "sample_centres")
     return 1
 
 

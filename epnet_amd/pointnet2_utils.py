@@ -104,13 +104,28 @@ def sample_and_gather(xyz: torch.Tensor, npoint: int, index: Optional[torch.Tens
     """the head of an SA module in one call: ``idx = furthest_point_sample(xyz, npoint)`` and
     ``new_xyz = gather_operation(xyz.transpose(1, 2), idx).transpose(1, 2)`` (pointnet2_modules.py:39-45) -- the
     sampling kernel has every selected point in registers, so the centres come with the indices. Same values;
-    no gradient flows to xyz here (use the composition when the coordinates need one)."""
+    no gradient flows to xyz here (use the composition when the coordinates need one).
+
+    Sampling pyramids: the centres returned here remember (as an attribute, like a scene index: only on this package's own
+    tensors, only while their version counter stands) for how many leading rounds the sampling was unambiguous. When such
+    centres are sampled again -- the next SA level -- scenes whose first npoint rounds were unambiguous get
+    ``idx = 0 .. npoint-1``: furthest point sampling is nested (include/epnet_ops.h, epnet_sample_centres_chain), so that IS
+    what the rounds would compute. Three of the four sampling kernels of the RPN pyramid disappear that way."""
     assert xyz.is_contiguous()
     batch, n = xyz.shape[0], xyz.shape[1]
     idx = _new(xyz, (batch, npoint), torch.int32)
     new_xyz = _new(xyz, (batch, npoint, 3))
-    _ext.sample_centres_wrapper(batch, n, npoint, xyz.detach(), index, idx, new_xyz)
-    return idx, _own(new_xyz)
+    prefix_in = None
+    known = getattr(xyz, "_epnet_fps_prefix", None)
+    if known is not None and getattr(xyz, "_epnet_owned", False) and not xyz.is_inference() and known[1] == xyz._version \
+            and known[2] == _capture_epoch():
+        prefix_in = known[0]
+    prefix_out = _new(xyz, (batch,), torch.int32)
+    _ext.sample_centres_wrapper(batch, n, npoint, xyz.detach(), index, idx, new_xyz, prefix_in, prefix_out)
+    new_xyz = _own(new_xyz)
+    if not new_xyz.is_inference():
+        new_xyz._epnet_fps_prefix = (prefix_out, new_xyz._version, _capture_epoch())
+    return idx, new_xyz
 
 
 _PYRAMID_STREAMS = {}

@@ -91,6 +91,9 @@ class SAStack:
         # 7.17 (everything in G) -> 6.60 (three_nn in S) -> see DESIGN.md section 5
         self.queries_in_s = (bool(int(os.environ.get("EPNET_SA_QUERIES_IN_S", "1"))) and with_fp and pipelined) if queries_in_s is None \
             else bool(queries_in_s and pipelined)
+        # levels 2.. of the pyramid sample the centres of the level above: with the chain of tie-free round counts handed from level
+        # to level (epnet_sample_centres_chain) their rounds are skipped wherever the answer is known to be 0 .. m-1
+        self.chain = bool(int(os.environ.get("EPNET_SA_CHAIN", "1"))) and fused_sampling
         self.tail_scales = int(os.environ.get("EPNET_SA_TAIL_SCALES", "0"))
         self.multi_query = bool(int(os.environ.get("EPNET_SA_MULTI_QUERY", "1")))  # both scales of a level in one launch
         self.multi_group = bool(int(os.environ.get("EPNET_SA_MULTI_GROUP", "1")))  # both groupings of a level in one call
@@ -113,7 +116,8 @@ class SAStack:
                 "new_xyz_t": torch.empty((batch, 3, m), dtype=f32, device=dev),
                 # what G reads from S, one set per pipeline parity
                 "sets": [{"new_xyz": torch.empty((batch, m, 3), dtype=f32, device=dev),
-                          "index": (torch.empty((index_bytes,), dtype=torch.uint8, device=dev) if index_bytes else None)}
+                          "index": (torch.empty((index_bytes,), dtype=torch.uint8, device=dev) if index_bytes else None),
+                          "prefix": torch.zeros((batch,), dtype=i32, device=dev)}   # tie-free leading rounds of this level's sampling
                          for _ in range(2 if pipelined else 1)],
                 "features": (torch.randn((batch, c, cur), generator=g, dtype=f32).to(dev) if c else None),
                 "scales": [],
@@ -157,7 +161,12 @@ class SAStack:
         if self.fused_sampling:   # FPS + gather of the centres in one kernel (epnet_sample_centres)
             if not self.fused:
                 L["xyz_t"].copy_(cur_xyz.transpose(1, 2))
-            ext.sample_centres_wrapper(b, n, m, cur_xyz, P["index"], L["fps_idx"], P["new_xyz"])
+            if self.chain:
+                lvl = self.levels.index(L)
+                prefix_in = self.levels[lvl - 1]["sets"][parity]["prefix"] if lvl > 0 else None
+                ext.sample_centres_wrapper(b, n, m, cur_xyz, P["index"], L["fps_idx"], P["new_xyz"], prefix_in, P["prefix"])
+            else:
+                ext.sample_centres_wrapper(b, n, m, cur_xyz, P["index"], L["fps_idx"], P["new_xyz"])
         else:                     # the reference module's sequence, op by op
             L["xyz_t"].copy_(cur_xyz.transpose(1, 2))            # pointnet2_modules.py:30
             L["temp"].fill_(1e10)                                # pointnet2_utils.py:26

@@ -1123,3 +1123,67 @@ def test_group_concat_long_rows_through_point_major_scratch(oracle, b, c, n, m, 
     only = torch.full((b, c, m, ns), float("nan"), device=DEV)
     ext.group_concat_wrapper(b, c, n, m, ns, None, None, feats, idx, only, False)
     np.testing.assert_array_equal(host(only), want_feat)
+
+
+def _lattice_cloud(n, seed):
+    rng = np.random.default_rng(seed)
+    base = rng.integers(-8, 9, size=(max(4, (n * 3) // 4), 3)).astype(np.float32) * np.float32(0.5)
+    pts = np.concatenate([base, base[rng.integers(0, len(base), size=n - len(base))]])
+    return pts[rng.permutation(n)].astype(np.float32)
+
+
+@pytest.mark.parametrize("kind,n,pyramid", [("kitti", 16384, (4096, 1024, 256, 64)), ("dup", 16384, (4096, 1024, 256, 64)),
+                                            ("ubox", 4096, (1024, 256, 64)), ("lattice", 4096, (1024, 256, 64)),
+                                            ("lattice", 16384, (4096, 1024, 256, 64)), ("kitti", 3000, (700, 300, 100))])
+def test_sampling_chain_matches_oracle_and_reports_exact_tie_rounds(oracle, kind, n, pyramid):
+    """epnet_sample_centres_chain over a whole pyramid: every level's indices and centres equal the oracle's (which runs the
+    reference's rounds on every level), whether a level took the identity (tie-free prefix known) or ran its rounds (ties: the
+    lattice cloud, duplicated rows). The first level's reported tie-free round count equals the count found by brute force"""
+    import sys
+    sys.path.insert(0, __import__("os").path.dirname(__file__))
+    from test_oracle_second_derivation import first_tie_round
+    from epnet_amd import pointnet2_cuda as ext
+    b = 3
+    clouds = np.stack([_lattice_cloud(n, 40 + s) if kind == "lattice" else rand_cloud(1, n, seed=60 + s, kind=kind)[0] for s in range(b)])
+    cur_h, cur = clouds, dev(clouds)
+    prefix_in = None
+    took_identity = []
+    for lvl, m in enumerate(pyramid):
+        nn = cur.shape[1]
+        index = ext.scene_index(cur)
+        idx = torch.full((b, m), -1, dtype=torch.int32, device=DEV)
+        centres = torch.full((b, m, 3), float("nan"), device=DEV)
+        prefix_out = torch.full((b,), -7, dtype=torch.int32, device=DEV)
+        ext.sample_centres_wrapper(b, nn, m, cur, index, idx, centres, prefix_in, prefix_out)
+        want = oracle.furthest_point_sampling(cur_h, m)
+        np.testing.assert_array_equal(host(idx), want, err_msg="level %d" % (lvl + 1))
+        want_c = np.take_along_axis(cur_h, want[:, :, None].astype(np.int64), axis=1)
+        np.testing.assert_array_equal(host(centres), want_c)
+        po = host(prefix_out)
+        if lvl == 0 and 1024 < nn <= 16384:   # the pruned kernels report ties exactly
+            for s_ in range(b):
+                tie, _ = first_tie_round(cur_h[s_], m, oracle.opt_n_threads(nn))
+                assert po[s_] == tie, (s_, po[s_], tie)
+        if prefix_in is not None:
+            took_identity.append((host(prefix_in) >= m).tolist())
+        assert (po >= 0).all() and (po <= max(m, int(host(prefix_in).max()) if prefix_in is not None else m)).all()
+        cur_h, cur, prefix_in = want_c, centres, prefix_out
+    if kind in ("kitti", "ubox") and n > 1024:
+        assert all(all(t) for t in took_identity)            # no ties: every deeper level is the identity
+    if kind == "lattice":
+        assert not any(any(t) for t in took_identity)        # ties from the first rounds on: every level ran its rounds
+
+
+def test_sample_and_gather_chains_through_the_centres():
+    """pointnet2_utils.sample_and_gather hands the knowledge on as an attribute of the centres it returns (only while their
+    version stands): the second call on them is the identity for a tie-free cloud, and a write to the centres ends it"""
+    from epnet_amd import pointnet2_utils as p2u
+    xyz = dev(rand_cloud(2, 16384, seed=5))
+    i1, c1 = p2u.sample_and_gather(xyz, 4096, p2u.scene_index(xyz))
+    assert hasattr(c1, "_epnet_fps_prefix") and host(c1._epnet_fps_prefix[0]).tolist() == [4096, 4096]
+    i2, c2 = p2u.sample_and_gather(c1, 1024, p2u.scene_index(c1))
+    assert torch.equal(i2, torch.arange(1024, dtype=torch.int32, device=DEV).repeat(2, 1)) and torch.equal(c2, c1[:, :1024])
+    assert torch.equal(i2, p2u.furthest_point_sample(c1, 1024))          # what the rounds compute
+    c1.mul_(1.0)                                                         # a write: the knowledge is void
+    i2b, _ = p2u.sample_and_gather(c1, 1024, None)
+    assert torch.equal(i2b, i2)

@@ -80,6 +80,45 @@ def test_fps_rank_rule_on_continuous_cloud(oracle):
     np.testing.assert_array_equal(oracle.furthest_point_sampling(xyz[None], 700)[0], want)
 
 
+def first_tie_round(xyz, m, bs):
+    """the first round of the furthest point sampling of ONE scene whose maximum running distance is held by several points
+    (m if there is none): numpy, the rank rule of fps_rank_rule"""
+    n = xyz.shape[0]
+    k = np.arange(n)
+    rank = bit_reverse(k % bs, int(math.log2(bs))).astype(np.int64) * (n // bs + 2) + k // bs
+    temp = np.full(n, 1e10, np.float32)
+    o, picks = 0, [0]
+    x, y, z = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    for it in range(1, m):
+        dx, dy, dz = x - x[o], y - y[o], z - z[o]
+        temp = np.minimum((dx * dx + dy * dy) + dz * dz, temp)
+        cand = np.flatnonzero(temp == temp.max())
+        if cand.size > 1:
+            return it, np.array(picks, np.int32)
+        o = int(cand[0])
+        picks.append(o)
+    return m, np.array(picks, np.int32)
+
+
+@pytest.mark.parametrize("kind,n,m,m2", [("kitti", 4096, 1024, 256), ("ubox", 2000, 500, 125), ("dup", 4096, 1024, 256), ("lattice", 4096, 1024, 256)])
+def test_fps_is_nested_while_the_maxima_are_unique(oracle, kind, n, m, m2):
+    """what epnet_sample_centres_chain rests on: sample a cloud (n -> m), then sample the samples (m -> m2) -- as long as the
+    maximum of every round of the first sampling was unique, the second sampling picks 0, 1, 2, ... (the reference's kernel on the
+    centres: the oracle). With ties the identity holds up to the first tied round."""
+    from epnet_amd import synth
+    xyz = clouds_with_duplicates(n, seed=3) if kind == "lattice" else synth.scenes(kind, 1, n, seed=11).numpy()[0]
+    tie, _ = first_tie_round(xyz, m, oracle.opt_n_threads(n))
+    idx = oracle.furthest_point_sampling(xyz[None], m)
+    centres = xyz[idx[0]]
+    idx2 = oracle.furthest_point_sampling(centres[None], m2)[0]
+    upto = min(tie, m2)
+    np.testing.assert_array_equal(idx2[:upto], np.arange(upto))
+    if kind in ("kitti", "ubox"):
+        assert tie == m            # continuous coordinates: no exact ties, the whole second level is the identity
+    if kind == "lattice":
+        assert tie < m2            # the lattice ties early: the case the chain must NOT shortcut
+
+
 def _tie_scene(n, at_unit_distance):
     xyz = np.zeros((1, n, 3), np.float32)
     xyz[0, list(at_unit_distance), 0] = 1.0
