@@ -366,7 +366,8 @@ __device__ __forceinline__ void set_rank(VH &rk2, int j, unsigned r) {  // j is 
 template <int kW, int PPT, bool kCtr, typename VF, typename VI, typename VH>
 __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, const VF &z, VI &t, const VH &rk2,
                                            float cx, float cy, float cz, int *__restrict__ idxs,
-                                           float *__restrict__ ctr, int *__restrict__ tie_free = nullptr) {
+                                           float *__restrict__ ctr, int *__restrict__ tie_free = nullptr, int known = 0,
+                                           const float *__restrict__ xyz_in_order = nullptr) {
     __shared__ unsigned long long s_key[3];
     __shared__ float4 s_rec[2][64 * kW];  // one record slot per thread
     __shared__ int s_idx[kIdxBufP];
@@ -398,7 +399,35 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
     if (q < 3) s_key[q] = 0ull;
     if (q == 0) s_idx[0] = 0;  // rank 0 == point 0
     if (kCtr && q < 3) s_ctr[q] = q == 0 ? cx : (q == 1 ? cy : cz);
+    // `known` leading samples are given (points 0 .. known-1 of the cloud in its own order: a sampling pyramid's chain,
+    // epnet_sample_centres_chain): their rounds need no selection, only the distance updates -- no cross-wave exchange, no barrier
+    if (known > kIdxBufP || known > m || !xyz_in_order || kCtr) known = 0;
+    for (int i = q; i < known; i += 64 * kW) s_idx[i] = (int)rank14(i);
     __syncthreads();
+    for (int it = 1; it < known; ++it) {
+        const float px = __builtin_amdgcn_fmed3f(cx, lox, hix), py = __builtin_amdgcn_fmed3f(cy, loy, hiy),
+                    pz = __builtin_amdgcn_fmed3f(cz, loz, hiz);
+        const float bdx = px - cx, bdy = py - cy, bdz = pz - cz;
+        const float L = bdx * bdx + bdy * bdy + bdz * bdz;
+        unsigned active = fold_parts<PPT>(__ballot(__float_as_int(L) < bm));
+        const float nx = xyz_in_order[it * 3 + 0], ny = xyz_in_order[it * 3 + 1], nz = xyz_in_order[it * 3 + 2];  // the next sample
+        while (active) {
+            const int j = (int)__builtin_ctz(active);
+            active &= active - 1u;
+            const float xj = x[j], yj = y[j], zj = z[j];
+            const int told = t[j];
+            __builtin_amdgcn_sched_barrier(0);
+            const float dx = xj - cx, dy = yj - cy, dz = zj - cz;
+            const float d = dx * dx + dy * dy + dz * dz;
+            const int tj = min(__float_as_int(d), told);
+            t[j] = tj;
+            const int gm = group_max<PPT>(tj);
+            bm = (sub == j) ? gm : bm;
+        }
+        cx = nx;
+        cy = ny;
+        cz = nz;
+    }
 
     // a strictly serial chain: when it shares a SIMD with a wide kernel (software-pipelined SA stack), every
     // instruction it has ready should issue first
@@ -416,7 +445,7 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
     // decides): up to that round the sequence of samples is a property of the coordinates alone (see epnet_sample_centres_chain)
     bool wave_multi = false;  // several points of this wave hold its maximum
     int tied_at = m;
-    for (int it = 1; it < m; ++it) {
+    for (int it = max(1, known); it < m; ++it) {
         EPNET_STAMP(t0);
         // A. which buckets can change?
         const float px = __builtin_amdgcn_fmed3f(cx, lox, hix), py = __builtin_amdgcn_fmed3f(cy, loy, hiy),
@@ -602,14 +631,15 @@ template <int kW, int PPT, bool kCtr>
 __global__ __launch_bounds__(64 * kW) void fps_indexed_kernel(int n, int m, const float4 *__restrict__ sorted,
                                                               float *__restrict__ temp, int *__restrict__ idxs,
                                                               float *__restrict__ ctr, const int *__restrict__ prefix_in,
-                                                              int *__restrict__ prefix_out) {
+                                                              int *__restrict__ prefix_out, const float *__restrict__ xyz) {
     typedef float vecf __attribute__((ext_vector_type(PPT)));
     typedef int veci __attribute__((ext_vector_type(PPT)));
     constexpr int NP = 64 * kW * PPT;
     __shared__ float s_first[4];
     const int q = threadIdx.x;
     const int lane = q & 63, wave = q >> 6;
-    if (prefix_in && prefix_in[blockIdx.x] >= m) return;  // the first m points ARE the samples (fps_prefix_kernel wrote them)
+    const int known = prefix_in ? prefix_in[blockIdx.x] : 0;
+    if (known >= m) return;  // the first m points ARE the samples (fps_prefix_kernel wrote them)
     sorted += (size_t)blockIdx.x * NP;
     if (temp) temp += (size_t)blockIdx.x * n;
     idxs += (size_t)blockIdx.x * m;
@@ -641,7 +671,8 @@ __global__ __launch_bounds__(64 * kW) void fps_indexed_kernel(int n, int m, cons
     }
     __syncthreads();
     fps_rounds<kW, PPT, kCtr>(m, x, y, z, t, rk2, s_first[0], s_first[1], s_first[2], idxs, ctr,
-                              prefix_out ? prefix_out + blockIdx.x : nullptr);
+                              prefix_out ? prefix_out + blockIdx.x : nullptr, known,
+                              xyz ? xyz + (size_t)blockIdx.x * n * 3 : nullptr);
     if (temp) {
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
@@ -1049,10 +1080,11 @@ static bool fps_detects_ties(int n, int m, bool indexed) {
 __global__ __launch_bounds__(256) void fps_prefix_kernel(int m, const int *__restrict__ skip, int *__restrict__ idx,
                                                          int *__restrict__ prefix_out, int init) {
     const int bs = blockIdx.x;
-    const bool known = skip && skip[bs] >= m;
-    if (threadIdx.x == 0 && prefix_out) prefix_out[bs] = known ? skip[bs] : init;
-    if (!known) return;
-    for (int i = threadIdx.x; i < m; i += 256) idx[(size_t)bs * m + i] = i;
+    const int have = skip ? skip[bs] : 0;
+    const bool known = have >= m;
+    if (threadIdx.x == 0 && prefix_out) prefix_out[bs] = known ? have : init;
+    // (a scene whose rounds do run rewrites its indices itself; the known prefix is the same there)
+    for (int i = threadIdx.x; i < min(have, m); i += 256) idx[(size_t)bs * m + i] = i;
 }
 
 // rows of the (B,N,3) cloud picked by idx (B,M): the centres of an SA level
@@ -1102,10 +1134,10 @@ static int fps_over_index(int b, int n, int m, const float *xyz, const void *ind
     do {                                                                                                                   \
         if (new_xyz && ctr_in_kernel)                                                                                      \
             hipLaunchKernelGGL((pruned::fps_indexed_kernel<W_, P_, true>), grid, dim3(64 * W_), 0, s, n, m, sorted, temp, \
-                               idx, new_xyz, skip, prefix_out);                                                            \
+                               idx, new_xyz, skip, prefix_out, xyz);                                                       \
         else                                                                                                               \
             hipLaunchKernelGGL((pruned::fps_indexed_kernel<W_, P_, false>), grid, dim3(64 * W_), 0, s, n, m, sorted, temp, \
-                               idx, (float *)nullptr, skip, prefix_out);                                                   \
+                               idx, (float *)nullptr, skip, prefix_out, xyz);                                              \
     } while (0)
             switch (scene_index_np(n)) {
                 case 2048: EPNET_FPS_INDEXED(4, 8); break;

@@ -1134,7 +1134,8 @@ def _lattice_cloud(n, seed):
 
 @pytest.mark.parametrize("kind,n,pyramid", [("kitti", 16384, (4096, 1024, 256, 64)), ("dup", 16384, (4096, 1024, 256, 64)),
                                             ("ubox", 4096, (1024, 256, 64)), ("lattice", 4096, (1024, 256, 64)),
-                                            ("lattice", 16384, (4096, 1024, 256, 64)), ("kitti", 3000, (700, 300, 100))])
+                                            ("lattice", 16384, (4096, 1024, 256, 64)), ("kitti", 3000, (700, 300, 100)),
+                                            ("kitti_twin", 16384, (4096, 1024, 256, 64))])
 def test_sampling_chain_matches_oracle_and_reports_exact_tie_rounds(oracle, kind, n, pyramid):
     """epnet_sample_centres_chain over a whole pyramid: every level's indices and centres equal the oracle's (which runs the
     reference's rounds on every level), whether a level took the identity (tie-free prefix known) or ran its rounds (ties: the
@@ -1144,7 +1145,16 @@ def test_sampling_chain_matches_oracle_and_reports_exact_tie_rounds(oracle, kind
     from test_oracle_second_derivation import first_tie_round
     from epnet_amd import pointnet2_cuda as ext
     b = 3
-    clouds = np.stack([_lattice_cloud(n, 40 + s) if kind == "lattice" else rand_cloud(1, n, seed=60 + s, kind=kind)[0] for s in range(b)])
+    if kind == "kitti_twin":
+        # a tie in the MIDDLE of the first level's rounds: the point picked in round 300 + 200 s gets an exact twin (written over a
+        # point that is never picked), so the deeper levels know a prefix of that length and resume their rounds from there
+        clouds = np.stack([rand_cloud(1, n, seed=60 + s, kind="kitti")[0] for s in range(b)])
+        for s_ in range(b):
+            seq = oracle.furthest_point_sampling(clouds[s_:s_ + 1], pyramid[0])[0]
+            never = np.setdiff1d(np.arange(n), seq)[7]
+            clouds[s_, never] = clouds[s_, seq[300 + 200 * s_]]
+    else:
+        clouds = np.stack([_lattice_cloud(n, 40 + s) if kind == "lattice" else rand_cloud(1, n, seed=60 + s, kind=kind)[0] for s in range(b)])
     cur_h, cur = clouds, dev(clouds)
     prefix_in = None
     took_identity = []
@@ -1172,6 +1182,9 @@ def test_sampling_chain_matches_oracle_and_reports_exact_tie_rounds(oracle, kind
         assert all(all(t) for t in took_identity)            # no ties: every deeper level is the identity
     if kind == "lattice":
         assert not any(any(t) for t in took_identity)        # ties from the first rounds on: every level ran its rounds
+    if kind == "kitti_twin":
+        assert took_identity[0] == [False, False, False]      # level 2 (1024 rounds) resumes after 300 / 500 / 700 known samples
+        assert took_identity[1] == [True, True, True]         # level 3 (256 rounds) lies inside every known prefix
 
 
 def test_sample_and_gather_chains_through_the_centres():
