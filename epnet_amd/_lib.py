@@ -54,7 +54,7 @@ SIGNATURES = {
     "epnet_scene_index_build": (_i, [_i, _i, _vp, _vp, _sz, _vp]),
     "epnet_furthest_point_sampling_indexed": (_i, [_i, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
     "epnet_sample_centres": (_i, [_i, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
-    "epnet_sample_centres_chain": (_i, [_i, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "epnet_sample_centres_chain": (_i, [_i, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "epnet_group_concat_multi": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "epnet_ball_query_indexed_multi": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "epnet_three_nn_indexed": (_i, [_i, _i, _i, _vp, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp]),

@@ -367,7 +367,7 @@ template <int kW, int PPT, bool kCtr, typename VF, typename VI, typename VH>
 __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, const VF &z, VI &t, const VH &rk2,
                                            float cx, float cy, float cz, int *__restrict__ idxs,
                                            float *__restrict__ ctr, int *__restrict__ tie_free = nullptr, int known = 0,
-                                           const float *__restrict__ xyz_in_order = nullptr) {
+                                           const float *__restrict__ xyz_in_order = nullptr, int detect_upto = 0x7fffffff) {
     __shared__ unsigned long long s_key[3];
     __shared__ float4 s_rec[2][64 * kW];  // one record slot per thread
     __shared__ int s_idx[kIdxBufP];
@@ -499,7 +499,7 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
                 ya = take ? yj : ya;
                 za = take ? zj : za;
             } while (cand);
-            if (tie_free) {
+            if (tie_free && it < detect_upto) {
                 const unsigned long long holders = __ballot(held > 0);
                 wave_multi = (holders & (holders - 1ull)) != 0ull || __ballot(held > 1) != 0ull;
             }
@@ -525,7 +525,7 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
         cx = rec.x;
         cy = rec.y;
         cz = rec.z;
-        if (tie_free && tied_at == m) {
+        if (tie_free && it < detect_upto && tied_at == m) {
             // this wave's (exact, possibly cached) maximum equals the winner's distance: a tie unless it IS the winner alone
             const bool mine = (int)((klo & 1023u) >> 6) == wave;
             if (wbest == (int)(unsigned)(kfull >> 32) && (!mine || wave_multi)) tied_at = it;
@@ -551,7 +551,7 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
     EPNET_STAMP(t_loop1);
     EPNET_ACC(6, t_loop0, t_loop1);
     EPNET_STATS_END;
-    if (tie_free && lane == 0) atomicMin(tie_free, tied_at);  // (initialised to m by the caller's launch sequence)
+    if (tie_free && lane == 0) atomicMin(tie_free, min(tied_at, detect_upto));  // (initialised to m by the caller's launch sequence)
     if (wave == 0) {
         const int base = (m - 1) & ~(kIdxBufP - 1);
         for (int e = lane; base + e < m; e += 64) idxs[base + e] = unrank14((unsigned)s_idx[e]);
@@ -566,7 +566,8 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
 template <int kW, int PPT>
 __global__ __launch_bounds__(64 * kW) void fps_pruned_kernel(int n, int m, const float *__restrict__ xyz,
                                                              float *__restrict__ temp, int *__restrict__ idxs,
-                                                             const int *__restrict__ skip, int *__restrict__ prefix_out) {
+                                                             const int *__restrict__ skip, int *__restrict__ prefix_out,
+                                                             int prefix_cap) {
     if (skip && skip[blockIdx.x] >= m) return;
     typedef float vecf __attribute__((ext_vector_type(PPT)));
     typedef int veci __attribute__((ext_vector_type(PPT)));
@@ -615,7 +616,7 @@ __global__ __launch_bounds__(64 * kW) void fps_pruned_kernel(int n, int m, const
         }
     }
     fps_rounds<kW, PPT, false>(m, x, y, z, t, rk2, xyz[0], xyz[1], xyz[2], idxs, nullptr,
-                               prefix_out ? prefix_out + blockIdx.x : nullptr);
+                               prefix_out ? prefix_out + blockIdx.x : nullptr, 0, nullptr, prefix_cap);
     if (temp) {
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
@@ -631,7 +632,8 @@ template <int kW, int PPT, bool kCtr>
 __global__ __launch_bounds__(64 * kW) void fps_indexed_kernel(int n, int m, const float4 *__restrict__ sorted,
                                                               float *__restrict__ temp, int *__restrict__ idxs,
                                                               float *__restrict__ ctr, const int *__restrict__ prefix_in,
-                                                              int *__restrict__ prefix_out, const float *__restrict__ xyz) {
+                                                              int *__restrict__ prefix_out, const float *__restrict__ xyz,
+                                                              int prefix_cap) {
     typedef float vecf __attribute__((ext_vector_type(PPT)));
     typedef int veci __attribute__((ext_vector_type(PPT)));
     constexpr int NP = 64 * kW * PPT;
@@ -672,7 +674,7 @@ __global__ __launch_bounds__(64 * kW) void fps_indexed_kernel(int n, int m, cons
     __syncthreads();
     fps_rounds<kW, PPT, kCtr>(m, x, y, z, t, rk2, s_first[0], s_first[1], s_first[2], idxs, ctr,
                               prefix_out ? prefix_out + blockIdx.x : nullptr, known,
-                              xyz ? xyz + (size_t)blockIdx.x * n * 3 : nullptr);
+                              xyz ? xyz + (size_t)blockIdx.x * n * 3 : nullptr, prefix_cap);
     if (temp) {
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
@@ -973,7 +975,7 @@ using namespace epnet;
 // left alone: fps_prefix_kernel has written their samples); prefix_out: per scene, receives the number of leading rounds of
 // THIS sampling whose maximum was unique (initialised by fps_prefix_kernel) where the kernel can tell. Both may be NULL.
 static int fps_plain(int b, int n, int m, const float *xyz, float *temp, int *idx, const int *skip, int *prefix_out,
-                     epnet_stream_t stream) {
+                     epnet_stream_t stream, int prefix_cap = 0x7fffffff) {
     EPNET_REQUIRE(b >= 0 && n >= 1 && m >= 0);
     if (b == 0 || m == 0) return EPNET_OK;  // the reference kernel returns at once for m <= 0
     EPNET_REQUIRE(xyz && idx);
@@ -998,7 +1000,7 @@ static int fps_plain(int b, int n, int m, const float *xyz, float *temp, int *id
         const int ppt = ppt_need <= 8 ? 8 : ppt_need <= 16 ? 16 : 32;
         const size_t lds = (size_t)(kCells + kCells / (kCells / (64 * waves)) + 64) * sizeof(int) + (size_t)64 * waves * ppt * 2;
 #define EPNET_FPS_PRUNED(W_, P_) \
-    hipLaunchKernelGGL((pruned::fps_pruned_kernel<W_, P_>), grid, dim3(64 * W_), lds, s, n, m, xyz, temp, idx, skip, prefix_out)
+    hipLaunchKernelGGL((pruned::fps_pruned_kernel<W_, P_>), grid, dim3(64 * W_), lds, s, n, m, xyz, temp, idx, skip, prefix_out, prefix_cap)
         if (waves == 8) {
             if (ppt == 8) EPNET_FPS_PRUNED(8, 8);
             else if (ppt == 16) EPNET_FPS_PRUNED(8, 16);
@@ -1063,7 +1065,7 @@ static int fps_plain(int b, int n, int m, const float *xyz, float *temp, int *id
 
 extern "C" int epnet_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp, int *idx,
                                              epnet_stream_t stream) {
-    return fps_plain(b, n, m, xyz, temp, idx, nullptr, nullptr, stream);
+    return fps_plain(b, n, m, xyz, temp, idx, nullptr, nullptr, stream, 0x7fffffff);
 }
 
 // does the kernel the dispatch above / below picks report its tie-free rounds? (the pruned kernels do)
@@ -1099,13 +1101,15 @@ __global__ __launch_bounds__(256) void gather_centres_kernel(int n, int m, const
 
 // shared by the two entry points below; new_xyz may be NULL
 static int fps_over_index(int b, int n, int m, const float *xyz, const void *index, size_t index_bytes, float *temp, int *idx,
-                          float *new_xyz, hipStream_t s, const int *skip = nullptr, int *prefix_out = nullptr) {
+                          float *new_xyz, hipStream_t s, const int *skip = nullptr, int *prefix_out = nullptr,
+                          int prefix_cap = 0x7fffffff) {
     const size_t need = scene_index_bytes(b, n);
     bool centres_done = false;
     int rc;
     const bool plain = need == 0 || !index || n <= 1024 || m <= 1 || (n > 16384 && !temp);
     if (skip || prefix_out) {
         EPNET_REQUIRE(idx && b <= 65535);
+        if (prefix_cap < 1) prefix_cap = 0x7fffffff;
         hipLaunchKernelGGL(fps_prefix_kernel, dim3(b), dim3(256), 0, s, m, skip, idx, prefix_out,
                            fps_detects_ties(n, m, !plain) ? m : 0);
         rc = check_launch("sampling prefix");
@@ -1113,7 +1117,7 @@ static int fps_over_index(int b, int n, int m, const float *xyz, const void *ind
     }
     // n <= 1024: the reference block size (hence the tie-break rank) depends on n; the one-wave kernel handles it
     if (plain) {
-        rc = fps_plain(b, n, m, xyz, temp, idx, skip, prefix_out, (epnet_stream_t)s);
+        rc = fps_plain(b, n, m, xyz, temp, idx, skip, prefix_out, (epnet_stream_t)s, prefix_cap);
     } else {
         EPNET_REQUIRE(idx);
         if (index_bytes < need) return EPNET_ENOMEM;
@@ -1134,10 +1138,10 @@ static int fps_over_index(int b, int n, int m, const float *xyz, const void *ind
     do {                                                                                                                   \
         if (new_xyz && ctr_in_kernel)                                                                                      \
             hipLaunchKernelGGL((pruned::fps_indexed_kernel<W_, P_, true>), grid, dim3(64 * W_), 0, s, n, m, sorted, temp, \
-                               idx, new_xyz, skip, prefix_out, xyz);                                                       \
+                               idx, new_xyz, skip, prefix_out, xyz, prefix_cap);                                           \
         else                                                                                                               \
             hipLaunchKernelGGL((pruned::fps_indexed_kernel<W_, P_, false>), grid, dim3(64 * W_), 0, s, n, m, sorted, temp, \
-                               idx, (float *)nullptr, skip, prefix_out, xyz);                                              \
+                               idx, (float *)nullptr, skip, prefix_out, xyz, prefix_cap);                                  \
     } while (0)
             switch (scene_index_np(n)) {
                 case 2048: EPNET_FPS_INDEXED(4, 8); break;
@@ -1184,13 +1188,15 @@ extern "C" int epnet_sample_centres(int b, int n, int m, const float *xyz, const
 // distances are the same fp32 values), so idx = 0 .. m'-1 -- bit for bit what the reference's kernel computes on the centres,
 // whose tie-break only matters among equal maxima. prefix_in[b] (or NULL) = the number of leading rounds of the sampling that
 // produced xyz in which the maximum was unique; scenes with prefix_in[b] >= m take the identity, the others run the rounds.
-// prefix_out[b] (or NULL) receives the same knowledge about THIS sampling's output (0 where the kernel cannot tell).
+// prefix_out[b] (or NULL) receives the same knowledge about THIS sampling's output (0 where the kernel cannot tell), looked
+// for during the first prefix_cap rounds only (<= 0: all rounds) -- the next level's sample count is all anybody will ask for.
 extern "C" int epnet_sample_centres_chain(int b, int n, int m, const float *xyz, const void *index, size_t index_bytes,
                                           float *temp, int *idx, float *new_xyz, const int *prefix_in, int *prefix_out,
-                                          epnet_stream_t stream) {
+                                          int prefix_cap, epnet_stream_t stream) {
     EPNET_REQUIRE(b >= 0 && n >= 1 && m >= 0);
     if (b == 0 || m == 0) return EPNET_OK;
     EPNET_REQUIRE(xyz && idx && new_xyz);
     if (m > n) prefix_in = nullptr;  // more samples than points: the sequence repeats points, nothing is known
-    return fps_over_index(b, n, m, xyz, index, index_bytes, temp, idx, new_xyz, (hipStream_t)stream, prefix_in, prefix_out);
+    return fps_over_index(b, n, m, xyz, index, index_bytes, temp, idx, new_xyz, (hipStream_t)stream, prefix_in, prefix_out,
+                          prefix_cap);
 }

@@ -194,11 +194,12 @@ def furthest_point_sampling_indexed_wrapper(b, n, m, points, index, temp, idx):
 
 
 @writes("idx", "new_xyz", "prefix_out")
-def sample_centres_wrapper(b, n, m, points, index, idx, new_xyz, prefix_in=None, prefix_out=None):
+def sample_centres_wrapper(b, n, m, points, index, idx, new_xyz, prefix_in=None, prefix_out=None, prefix_cap=0):
     """furthest_point_sampling from a fresh state + gather of the selected rows: idx (B,M) and new_xyz (B,M,3).
     prefix_in / prefix_out (int32 (B,) or None): the sampling pyramid's chain of knowledge (include/epnet_ops.h,
     epnet_sample_centres_chain): scenes whose input is known to be an unambiguous furthest-point sequence of at least m
-    samples get idx = 0 .. m-1 without running the rounds -- the same result"""
+    samples get idx = 0 .. m-1 without running the rounds -- the same result; prefix_cap = the next level's sample count
+    (ties are looked for in that many rounds only; 0 = all)"""
     pp, pi, pn = dev_ptr(points, "points", _F), dev_ptr(idx, "idx", _I), dev_ptr(new_xyz, "new_xyz", _F)
     need(points, b * n * 3, "points"); need(idx, b * m, "idx"); need(new_xyz, b * m * 3, "new_xyz")
     px, nb = _index_args(index, points)
@@ -214,7 +215,8 @@ def sample_centres_wrapper(b, n, m, points, index, idx, new_xyz, prefix_in=None,
                 need(prefix_in, b, "prefix_in")
             if prefix_out is not None:
                 need(prefix_out, b, "prefix_out")
-            _lib.check(_lib.lib().epnet_sample_centres_chain(b, n, m, pp, px, nb, pt, pi, pn, pin, pout, s), "sample_centres")
+            _lib.check(_lib.lib().epnet_sample_centres_chain(b, n, m, pp, px, nb, pt, pi, pn, pin, pout, int(prefix_cap), s),
+                       "sample_centres")
     return 1
 
 

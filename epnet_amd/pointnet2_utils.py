@@ -100,7 +100,7 @@ def scene_index(xyz: torch.Tensor, cached_only: bool = False) -> Optional[torch.
     return index
 
 
-def sample_and_gather(xyz: torch.Tensor, npoint: int, index: Optional[torch.Tensor] = None):
+def sample_and_gather(xyz: torch.Tensor, npoint: int, index: Optional[torch.Tensor] = None, next_npoint: int = 0):
     """the head of an SA module in one call: ``idx = furthest_point_sample(xyz, npoint)`` and
     ``new_xyz = gather_operation(xyz.transpose(1, 2), idx).transpose(1, 2)`` (pointnet2_modules.py:39-45) -- the
     sampling kernel has every selected point in registers, so the centres come with the indices. Same values;
@@ -121,7 +121,7 @@ def sample_and_gather(xyz: torch.Tensor, npoint: int, index: Optional[torch.Tens
             and known[2] == _capture_epoch():
         prefix_in = known[0]
     prefix_out = _new(xyz, (batch,), torch.int32)
-    _ext.sample_centres_wrapper(batch, n, npoint, xyz.detach(), index, idx, new_xyz, prefix_in, prefix_out)
+    _ext.sample_centres_wrapper(batch, n, npoint, xyz.detach(), index, idx, new_xyz, prefix_in, prefix_out, int(next_npoint))
     new_xyz = _own(new_xyz)
     if not new_xyz.is_inference():
         new_xyz._epnet_fps_prefix = (prefix_out, new_xyz._version, _capture_epoch())
@@ -151,7 +151,7 @@ def sample_pyramid(xyz: torch.Tensor, npoints):
         for k, m in enumerate(npoints):
             src = xyz if k == 0 else cur          # the tensor object the SA module of this level will receive
             index = scene_index(src)
-            idx, new_xyz = sample_and_gather(src, int(m), index)
+            idx, new_xyz = sample_and_gather(src, int(m), index, int(npoints[k + 1]) if k + 1 < len(npoints) else 1)
             event = torch.cuda.Event()
             event.record(side)
             for t in (idx, new_xyz, index):       # allocated on the side stream, consumed on the caller's

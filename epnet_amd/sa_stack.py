@@ -164,7 +164,8 @@ class SAStack:
             if self.chain:
                 lvl = self.levels.index(L)
                 prefix_in = self.levels[lvl - 1]["sets"][parity]["prefix"] if lvl > 0 else None
-                ext.sample_centres_wrapper(b, n, m, cur_xyz, P["index"], L["fps_idx"], P["new_xyz"], prefix_in, P["prefix"])
+                nxt = self.levels[lvl + 1]["m"] if lvl + 1 < len(self.levels) else 1
+                ext.sample_centres_wrapper(b, n, m, cur_xyz, P["index"], L["fps_idx"], P["new_xyz"], prefix_in, P["prefix"], nxt)
             else:
                 ext.sample_centres_wrapper(b, n, m, cur_xyz, P["index"], L["fps_idx"], P["new_xyz"])
         else:                     # the reference module's sequence, op by op

@@ -218,9 +218,11 @@ int epnet_sample_centres(int b, int n, int m, const float *xyz, const void *inde
  * furthest-point samples of that sequence -- idx = 0 .. m-1, bit for bit what sampling_gpu.cu:94-209 computes on the centres
  * (its tie-break matters among equal maxima only). prefix_in (b ints or NULL): leading rounds of the sampling that produced xyz
  * in which the maximum was unique (= the prefix_out of that call); scenes with prefix_in[b] >= m take the identity, the others
- * run the rounds. prefix_out (b ints or NULL): the same knowledge about this call's output, 0 where the kernel cannot tell. */
+ * run the rounds. prefix_out (b ints or NULL): the same knowledge about this call's output (at least that many rounds), 0 where
+ * the kernel cannot tell; ties are looked for during the first prefix_cap rounds only (<= 0: all) -- pass the next level's m. */
 int epnet_sample_centres_chain(int b, int n, int m, const float *xyz, const void *index, size_t index_bytes, float *temp,
-                               int *idx, float *new_xyz, const int *prefix_in, int *prefix_out, epnet_stream_t stream);
+                               int *idx, float *new_xyz, const int *prefix_in, int *prefix_out, int prefix_cap,
+                               epnet_stream_t stream);
 /* same contract as epnet_three_nn (interpolate_gpu.cu:55-74); known_index = scene index of `known` (NULL: plain
  * path), unknown_index = scene index of `unknown` or NULL */
 int epnet_three_nn_indexed(int b, int n, int m, const float *unknown, const float *known, const void *unknown_index,
