@@ -89,7 +89,8 @@ class SAStack:
         # issue bound, 0.57 ms) then move to the tail of stage S as well, behind the sampling and the neighbour search of the same
         # batch, and hand their index tensors to the next step's grouping (double-buffered). 256-scene step with FP ops:
         # 7.17 (everything in G) -> 6.60 (three_nn in S) -> see DESIGN.md section 5
-        self.queries_in_s = (bool(int(os.environ.get("EPNET_SA_QUERIES_IN_S", "1"))) and with_fp and pipelined) if queries_in_s is None \
+        env_q = int(os.environ.get("EPNET_SA_QUERIES_IN_S", "1"))   # 0: never, 1: with the FP ops in the step, 2: always
+        self.queries_in_s = (pipelined and (env_q == 2 or (env_q == 1 and with_fp))) if queries_in_s is None \
             else bool(queries_in_s and pipelined)
         # levels 2.. of the pyramid sample the centres of the level above: with the chain of tie-free round counts handed from level
         # to level (epnet_sample_centres_chain) their rounds are skipped wherever the answer is known to be 0 .. m-1
