@@ -29,6 +29,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "dpp.h"
 #include "spatial.h"
@@ -445,7 +447,10 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
     // decides): up to that round the sequence of samples is a property of the coordinates alone (see epnet_sample_centres_chain)
     bool wave_multi = false;  // several points of this wave hold its maximum
     int tied_at = m;
-    for (int it = max(1, known); it < m; ++it) {
+    // one round; kTies: also look for a second holder of the round's maximum (only the rounds a later level can ask about pay
+    // for that: the two instantiations of the body are run one after the other)
+    auto round = [&](auto ties_tag, const int it) __attribute__((always_inline)) {
+        constexpr bool kTies = decltype(ties_tag)::value;
         EPNET_STAMP(t0);
         // A. which buckets can change?
         const float px = __builtin_amdgcn_fmed3f(cx, lox, hix), py = __builtin_amdgcn_fmed3f(cy, loy, hiy),
@@ -499,7 +504,7 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
                 ya = take ? yj : ya;
                 za = take ? zj : za;
             } while (cand);
-            if (tie_free && it < detect_upto) {
+            if (kTies) {
                 const unsigned long long holders = __ballot(held > 0);
                 wave_multi = (holders & (holders - 1ull)) != 0ull || __ballot(held > 1) != 0ull;
             }
@@ -525,10 +530,10 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
         cx = rec.x;
         cy = rec.y;
         cz = rec.z;
-        if (tie_free && it < detect_upto && tied_at == m) {
+        if (kTies && tied_at == m) {
             // this wave's (exact, possibly cached) maximum equals the winner's distance: a tie unless it IS the winner alone
             const bool mine = (int)((klo & 1023u) >> 6) == wave;
-            if (wbest == (int)(unsigned)(kfull >> 32) && (!mine || wave_multi)) tied_at = it;
+            if (__ballot(wbest == (int)(unsigned)(kfull >> 32) && (!mine || wave_multi)) != 0ull) tied_at = it;  // (scalar branch)
         }
         const int kb2 = kb == 0 ? 2 : kb - 1;  // == (it + 2) % 3: last read in round it-1, next used in round it+2
         kb = kb == 2 ? 0 : kb + 1;
@@ -547,7 +552,13 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
         }
         EPNET_STAMP(t5);
         EPNET_ACC(1, t0, t1); EPNET_ACC(2, t1, t2); EPNET_ACC(3, t2, t3); EPNET_ACC(4, t3, t4); EPNET_ACC(5, t4, t5);
+    };
+    int it0 = max(1, known);
+    if (tie_free) {
+        const int upto = min(m, detect_upto);
+        for (; it0 < upto; ++it0) round(std::true_type{}, it0);
     }
+    for (; it0 < m; ++it0) round(std::false_type{}, it0);
     EPNET_STAMP(t_loop1);
     EPNET_ACC(6, t_loop0, t_loop1);
     EPNET_STATS_END;
