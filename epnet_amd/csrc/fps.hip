@@ -446,7 +446,7 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
     // the first round whose maximum is NOT unique (several points at the maximum running distance: the reference's tie-break
     // decides): up to that round the sequence of samples is a property of the coordinates alone (see epnet_sample_centres_chain)
     bool wave_multi = false;  // several points of this wave hold its maximum
-    int tied_at = m;
+    int tied_v = 0x7fffffff;  // wave-uniform, kept scalar
     // one round; kTies: also look for a second holder of the round's maximum (only the rounds a later level can ask about pay
     // for that: the two instantiations of the body are run one after the other)
     auto round = [&](auto ties_tag, const int it) __attribute__((always_inline)) {
@@ -530,10 +530,12 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
         cx = rec.x;
         cy = rec.y;
         cz = rec.z;
-        if (kTies && tied_at == m) {
-            // this wave's (exact, possibly cached) maximum equals the winner's distance: a tie unless it IS the winner alone
+        if (kTies) {
+            // this wave's (exact, possibly cached) maximum equals the winner's distance: a tie unless it IS the winner alone.
+            // Branch-free (a scalar branch here would put a VALU -> SALU round trip on every wave's critical path)
             const bool mine = (int)((klo & 1023u) >> 6) == wave;
-            if (__ballot(wbest == (int)(unsigned)(kfull >> 32) && (!mine || wave_multi)) != 0ull) tied_at = it;  // (scalar branch)
+            const bool other = !mine || wave_multi;
+            tied_v = min(tied_v, __builtin_amdgcn_readfirstlane((wbest == (int)(unsigned)(kfull >> 32) && other) ? it : 0x7fffffff));  // an SGPR
         }
         const int kb2 = kb == 0 ? 2 : kb - 1;  // == (it + 2) % 3: last read in round it-1, next used in round it+2
         kb = kb == 2 ? 0 : kb + 1;
@@ -562,7 +564,7 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
     EPNET_STAMP(t_loop1);
     EPNET_ACC(6, t_loop0, t_loop1);
     EPNET_STATS_END;
-    if (tie_free && lane == 0) atomicMin(tie_free, min(tied_at, detect_upto));  // (initialised to m by the caller's launch sequence)
+    if (tie_free && lane == 0) atomicMin(tie_free, min(min(tied_v, m), detect_upto));  // (initialised to m by the caller's launch sequence)
     if (wave == 0) {
         const int base = (m - 1) & ~(kIdxBufP - 1);
         for (int e = lane; base + e < m; e += 64) idxs[base + e] = unrank14((unsigned)s_idx[e]);
