@@ -179,7 +179,8 @@ def verify_scene(stack, xyz, scene):
         for S in L["scales"]:
             stag = tag + "r%g." % S["radius"]
             bq = oracle.ball_query(S["radius"], S["ns"], cur, new_xyz)
-            same(stag + "ball_idx", S["idx"][scene:scene + 1], bq)
+            for k, idx_set in enumerate(S.get("idx_sets", [S["idx"]])):   # (one per pipeline parity when the queries run in stage S)
+                same(stag + "ball_idx[set %d]" % k, idx_set[scene:scene + 1], bq)
             want_xyz = oracle.group_points(cur_t, bq) - new_xyz.transpose(0, 2, 1)[:, :, :, None]   # pointnet2_utils.py:250-251
             want_feat = None if feats is None else oracle.group_points(feats, bq)
             if stack.fused:

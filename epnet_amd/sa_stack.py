@@ -92,6 +92,11 @@ class SAStack:
         env_q = int(os.environ.get("EPNET_SA_QUERIES_IN_S", "1"))   # 0: never, 1: with the FP ops in the step, 2: always
         self.queries_in_s = (pipelined and (env_q == 2 or (env_q == 1 and with_fp))) if queries_in_s is None \
             else bool(queries_in_s and pipelined)
+        # ... or only the queries of some levels (0-based, "1,2,3" = levels 2-4): balances the two stages when stage S is the shorter
+        env_lv = os.environ.get("EPNET_SA_S_QUERY_LEVELS", "")
+        self.s_query_levels = frozenset(range(len(npoints))) if self.queries_in_s else \
+            (frozenset(int(v) for v in env_lv.split(",") if v.strip()) if (env_lv and pipelined) else frozenset())
+        self.queries_in_s = len(self.s_query_levels) == len(npoints)
         # levels 2.. of the pyramid sample the centres of the level above: with the chain of tie-free round counts handed from level
         # to level (epnet_sample_centres_chain) their rounds are skipped wherever the answer is known to be 0 .. m-1
         self.chain = bool(int(os.environ.get("EPNET_SA_CHAIN", "1"))) and fused_sampling
@@ -125,7 +130,8 @@ class SAStack:
             }
             for radius, ns in zip(radii[lvl], nsamples[lvl]):
                 S = {"radius": radius, "ns": ns, "idx": torch.empty((batch, m, ns), dtype=i32, device=dev)}
-                S["idx_sets"] = [S["idx"]] + ([torch.empty((batch, m, ns), dtype=i32, device=dev)] if self.queries_in_s else [])
+                S["idx_sets"] = [S["idx"]] + ([torch.empty((batch, m, ns), dtype=i32, device=dev)]
+                                              if lvl in self.s_query_levels else [])
                 if fused:
                     S["grouped"] = torch.empty((batch, 3 + c, m, ns), dtype=f32, device=dev)
                 else:
@@ -273,24 +279,26 @@ class SAStack:
             # for the first 2.5 ms of the step: the LDS-staged feature gathers of levels 2-4 (few registers) run
             # beside it, the level-1 ball queries (occupancy-hungry) after it.
             inputs = [prev_xyz] + [L["sets"][1 - parity]["new_xyz"] for L in self.levels[:-1]]
-            if self.queries_in_s:   # the index tensors of the previous batch are ready: stage G is the groupings alone
-                for L, cur in list(zip(self.levels, inputs))[1:] + [(first, prev_xyz)]:
-                    self._group_scales(L, cur, 1 - parity)
-            else:
-                deep = list(zip(self.levels, inputs))[1:]
-                for k, (L, cur) in enumerate(deep):
-                    if k == 0:       # level 2 (indexed queries: few registers) then its gathers beside the level-1 FPS
-                        self._group_level(L, cur, 1 - parity)
-                for L, cur in deep[1:]:
+            # (the index tensors of the levels in s_query_levels are ready: their part of stage G is the groupings alone)
+            in_s = self.s_query_levels
+            deep = list(enumerate(zip(self.levels, inputs)))[1:]
+            for lvl, (L, cur) in deep[:1]:   # level 2 (indexed queries: few registers) then its gathers beside the level-1 FPS
+                if lvl not in in_s:
                     self._query_level(L, cur, 1 - parity)
-                for L, cur in deep[1:]:
-                    self._group_scales(L, cur, 1 - parity)
-                if self.tail_scales == 0:
-                    self._group_level(first, prev_xyz, 1 - parity)
-                else:
-                    for S in first["scales"][self.tail_scales:]:
-                        self._query_scale(first, S, prev_xyz, 1 - parity)
-                        self._group_scale(first, S, prev_xyz, 1 - parity)
+                self._group_scales(L, cur, 1 - parity)
+            for lvl, (L, cur) in deep[1:]:
+                if lvl not in in_s:
+                    self._query_level(L, cur, 1 - parity)
+            for lvl, (L, cur) in deep[1:]:
+                self._group_scales(L, cur, 1 - parity)
+            if 0 in in_s:
+                self._group_scales(first, prev_xyz, 1 - parity)
+            elif self.tail_scales == 0:
+                self._group_level(first, prev_xyz, 1 - parity)
+            else:
+                for S in first["scales"][self.tail_scales:]:
+                    self._query_scale(first, S, prev_xyz, 1 - parity)
+                    self._group_scale(first, S, prev_xyz, 1 - parity)
             if self.with_fp:
                 self._interpolate_fp(1 - parity)
         cur = xyz
@@ -298,19 +306,20 @@ class SAStack:
             cur = self._sample_level(L, cur, parity, index_built=L is first)
         if self.with_fp:
             self._search_fp(xyz, parity)
-        if self.queries_in_s:
+        if self.s_query_levels:
             self._queries_of(xyz, parity)
         # if the sampling chain is the shorter stage it can take level-1 scales of stage G as its tail
-        for S in first["scales"][:(0 if self.queries_in_s else self.tail_scales)]:
+        for S in first["scales"][:(0 if 0 in self.s_query_levels else self.tail_scales)]:
             self._query_scale(first, S, prev_xyz, 1 - parity)
             self._group_scale(first, S, prev_xyz, 1 - parity)
         main.wait_stream(side)
 
     def _queries_of(self, xyz, parity):
-        """the ball queries of every level for the batch whose centres / indices are in set `parity`"""
+        """the ball queries of the levels in s_query_levels for the batch whose centres / indices are in set `parity`"""
         cur = xyz
-        for L in self.levels:
-            self._query_level(L, cur, parity)
+        for lvl, L in enumerate(self.levels):
+            if lvl in self.s_query_levels:
+                self._query_level(L, cur, parity)
             cur = L["sets"][parity]["new_xyz"]
 
     def _search_fp(self, xyz, parity):
@@ -354,7 +363,7 @@ class SAStack:
                 cur = self._sample_level(L, cur, parity)
             if self.with_fp:
                 self._search_fp(xyz, parity)
-            if self.queries_in_s:
+            if self.s_query_levels:
                 self._queries_of(xyz, parity)
 
     def _step_eager(self, k):
