@@ -401,6 +401,7 @@ def main():
         return time.perf_counter() - t0, stack, xyz
 
     elapsed, stack, xyz = time_stack(args.batch, args.steps, args.warmup)
+    stack_s_levels = stack.s_query_levels
     reduce_dev = dev if dist.is_initialized() and dist.get_backend() == "nccl" else "cpu"
     elapsed = scene_shard.max_over_ranks(elapsed, device=reduce_dev)
     points_per_step = world * args.batch * args.points
@@ -539,7 +540,8 @@ def main():
             "config": {"workload": "%d x %d-pt %s scenes per GPU per step through %s, %s launch"
                                    % (args.batch, args.points, args.kind, shape, "eager" if args.no_graph else "HIP-graph"),
                        "baseline_config": args.config, "levels": levels,
-                       "scenes_per_gpu": args.batch, "software_pipelined": bool(args.pipelined), "points_per_scene": args.points, "parallelism": "scene-parallel x%d" % world},
+                       "scenes_per_gpu": args.batch, "software_pipelined": bool(args.pipelined),
+                       "ball_queries_in_stage_s_levels": [v + 1 for v in sorted(stack_s_levels)], "points_per_scene": args.points, "parallelism": "scene-parallel x%d" % world},
             "points_per_s_per_gpu": round(value / world, 1),
             "stack_algorithmic_GBps_per_gpu": round(stack_gbs, 2), "stack_hbm_frac": round(stack_gbs / HBM_PEAK_GBS, 6),
             "device_copy_GBps": round(copy_gbs, 1), "stack_frac_of_device_copy": round(stack_gbs / copy_gbs, 6),

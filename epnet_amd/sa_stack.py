@@ -73,7 +73,7 @@ def fp_algorithmic_bytes(fp=RPN_FP):
 class SAStack:
     def __init__(self, batch, n=16384, device="cuda", npoints=RPN_NPOINTS, radii=RPN_RADII, nsamples=RPN_NSAMPLES,
                  feat_channels=RPN_FEAT_CHANNELS, with_fp=False, fp=RPN_FP, seed=0, overlap=True, fused=True,
-                 shared_index=True, pipelined=False, fused_sampling=False, queries_in_s=None):
+                 shared_index=True, pipelined=False, fused_sampling=False, queries_in_s=None, s_query_levels=None):
         self.batch, self.n = batch, n
         # overlap: FPS/gather of level l+1 depend only on the centres of level l (never on features), so
         # the sampling chain runs ahead on the launch stream while ball query + grouping of each level
@@ -85,18 +85,33 @@ class SAStack:
         # epnet_sample_centres (FPS + row gather of the centres: 3 launches per level with the index build) instead of the
         # reference module's op-by-op sequence (transpose, fill, FPS, gather, transpose: 6 launches): 256-scene step 3.78 -> 3.66 ms
         self.fused_sampling = fused_sampling
-        # With the FP ops in the step stage G carries 2.2 ms of interpolation on top of the groupings: the ball queries (latency /
-        # issue bound, 0.57 ms) then move to the tail of stage S as well, behind the sampling and the neighbour search of the same
-        # batch, and hand their index tensors to the next step's grouping (double-buffered). 256-scene step with FP ops:
-        # 7.17 (everything in G) -> 6.60 (three_nn in S) -> see DESIGN.md section 5
-        env_q = int(os.environ.get("EPNET_SA_QUERIES_IN_S", "1"))   # 0: never, 1: with the FP ops in the step, 2: always
-        self.queries_in_s = (pipelined and (env_q == 2 or (env_q == 1 and with_fp))) if queries_in_s is None \
-            else bool(queries_in_s and pipelined)
-        # ... or only the queries of some levels (0-based, "1,2,3" = levels 2-4): balances the two stages when stage S is the shorter
-        env_lv = os.environ.get("EPNET_SA_S_QUERY_LEVELS", "")
-        self.s_query_levels = frozenset(range(len(npoints))) if self.queries_in_s else \
-            (frozenset(int(v) for v in env_lv.split(",") if v.strip()) if (env_lv and pipelined) else frozenset())
-        self.queries_in_s = len(self.s_query_levels) == len(npoints)
+        # Which ball queries run at the tail of stage S (behind the sampling -- and the neighbour search -- of the same batch, handing
+        # their index tensors to the next step's grouping, double-buffered) instead of in front of their grouping in stage G:
+        #  * with the FP ops in the step stage G carries 2.2 ms of interpolation on top of the groupings: all of them
+        #    (256-scene step with FP ops: 7.17 (everything in G) -> 6.60 (three_nn in S) -> 6.2 ms);
+        #  * without them, from ~192 scenes per step stage G (bandwidth-bound, grows with the batch) is the longer stage beside the
+        #    latency-bound sampling chain: the level-2 queries go to stage S (256 scenes: 3.45 - 3.55 -> 3.18 - 3.26 ms, 512 scenes
+        #    7.04 -> 6.54; all levels: 3.52, level 1 alone: 3.49; at 128 scenes stage S is the longer one: 2.62 -> 2.69, so not there).
+        # EPNET_SA_QUERIES_IN_S = 0: none, 1 (default): as above, 2: all levels; EPNET_SA_S_QUERY_LEVELS = "1,3": these (0-based)
+        env_q = int(os.environ.get("EPNET_SA_QUERIES_IN_S", "1"))
+        env_lv = os.environ.get("EPNET_SA_S_QUERY_LEVELS")
+        every = frozenset(range(len(npoints)))
+        if not pipelined:
+            chosen = frozenset()
+        elif s_query_levels is not None:
+            chosen = frozenset(int(v) for v in s_query_levels)
+        elif queries_in_s is not None:
+            chosen = every if queries_in_s else frozenset()
+        elif env_lv is not None:
+            chosen = frozenset(int(v) for v in env_lv.split(",") if v.strip())
+        elif env_q == 2 or (env_q == 1 and with_fp):
+            chosen = every
+        elif env_q == 1 and batch * n >= 192 * 16384:
+            chosen = frozenset({1})
+        else:
+            chosen = frozenset()
+        self.s_query_levels = chosen & every
+        self.queries_in_s = self.s_query_levels == every
         # levels 2.. of the pyramid sample the centres of the level above: with the chain of tie-free round counts handed from level
         # to level (epnet_sample_centres_chain) their rounds are skipped wherever the answer is known to be 0 .. m-1
         self.chain = bool(int(os.environ.get("EPNET_SA_CHAIN", "1"))) and fused_sampling

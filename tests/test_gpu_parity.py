@@ -1043,24 +1043,28 @@ def test_ops_follow_the_current_stream_and_graph_replay(oracle):
     np.testing.assert_array_equal(eager[0], oracle.furthest_point_sampling(xyz_h.numpy(), 1024))
 
 
-@pytest.mark.parametrize("with_fp,kind", [(False, "kitti"), (True, "kitti"), (False, "dup")])
-def test_the_benchs_own_configuration_against_the_oracle(oracle, with_fp, kind):
+@pytest.mark.parametrize("with_fp,kind,in_s", [(False, "kitti", (1,)), (True, "kitti", None), (False, "dup", ()), (False, "dup", (1, 3)),
+                                               (True, "kitti", (1, 2, 3))])
+def test_the_benchs_own_configuration_against_the_oracle(oracle, with_fp, kind, in_s):
     """exactly what bench.py times -- SAStack at 16384 points, software-pipelined, captured into two HIP graphs, the
     kernels the 256-scene run uses (fps_indexed_kernel<8,32>, the multi-scale ball query, group_concat_multi) -- with
     every fps_idx / centre / ball-query idx / grouped tensor of every level compared with the ORACLE directly
-    (bench.verify_scene, the check the bench itself prints as `verified`)"""
+    (bench.verify_scene, the check the bench itself prints as `verified`). in_s: the levels whose ball queries run at the tail of
+    stage S ((1,) is what the 256-scene bench line uses, None = the stack's own choice: all of them with the FP ops)"""
     import bench
     from epnet_amd import sa_stack, synth
     b = 2
     xyz = synth.scenes(kind, b, 16384, seed=77).to(DEV)
-    stack = sa_stack.SAStack(b, n=16384, device=DEV, with_fp=with_fp, seed=5, pipelined=True, fused_sampling=True)
+    stack = sa_stack.SAStack(b, n=16384, device=DEV, with_fp=with_fp, seed=5, pipelined=True, fused_sampling=True, s_query_levels=in_s)
+    assert stack.s_query_levels == (frozenset(range(4)) if in_s is None else frozenset(in_s))
     stack.capture(xyz)
     for L in stack.levels:        # nothing of the capture-time warm-up may survive into the comparison
         L["fps_idx"].fill_(-1)
         for P in L["sets"]:
             P["new_xyz"].zero_()    # (read as centres by the first replay's grouping stage: keep them finite)
         for S in L["scales"]:
-            S["idx"].zero_()
+            for idx_set in S["idx_sets"]:   # (read by the next step's grouping when the queries run in stage S: valid indices)
+                idx_set.zero_()
             S["grouped"].fill_(float("nan"))
     for F in stack.fp_bufs:   # (the neighbour indices are read by the NEXT step's interpolation: they stay valid indices)
         F["out"].fill_(float("nan"))
@@ -1074,7 +1078,7 @@ def test_the_benchs_own_configuration_against_the_oracle(oracle, with_fp, kind):
         assert bench.verify_scene(stack, stack.static_xyz, scene) == []
     # the checker does notice a wrong buffer
     stack.levels[1]["scales"][0]["idx"][0, 5, 3] += 1
-    assert bench.verify_scene(stack, stack.static_xyz, 0) == ["level2.r0.5.ball_idx"]
+    assert bench.verify_scene(stack, stack.static_xyz, 0) == ["level2.r0.5.ball_idx[set 0]"]
 
 
 def test_config5_stack_against_the_oracle(oracle):
