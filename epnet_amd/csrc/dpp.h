@@ -75,4 +75,26 @@ __device__ __forceinline__ float row16_maxf(float v) {
     return v;
 }
 
+// The boxes of the four 16-lane rows of a wave's points (x, y, z per lane): per-row minimum and maximum of each coordinate in every
+// lane of the row. Written as 24 v_min / v_max with the DPP lane move folded into the instruction: through fminf / fmaxf the compiler
+// emits three instructions per step (DPP move, a canonicalising v_max x,x the IEEE mode asks of minnum, the min itself). The six
+// chains are interleaved, so every instruction reads registers written at least five instructions earlier (a DPP read needs two
+// wait states after the write; the s_nops cover the inputs and whatever reads the results next). All lanes of the wave must be active. A NaN coordinate drops
+// out of its row's box (v_min / v_max return the other operand), exactly like fminf / fmaxf.
+__device__ __forceinline__ void row16_boxes(float x, float y, float z, float &lx, float &hx, float &ly, float &hy, float &lz,
+                                            float &hz) {
+#define EPNET_ROWBOX_STEP(ctl)                                         \
+    "v_min_f32_dpp %0, %0, %0 " ctl " row_mask:0xf bank_mask:0xf\n"     \
+    "v_max_f32_dpp %1, %1, %1 " ctl " row_mask:0xf bank_mask:0xf\n"     \
+    "v_min_f32_dpp %2, %2, %2 " ctl " row_mask:0xf bank_mask:0xf\n"     \
+    "v_max_f32_dpp %3, %3, %3 " ctl " row_mask:0xf bank_mask:0xf\n"     \
+    "v_min_f32_dpp %4, %4, %4 " ctl " row_mask:0xf bank_mask:0xf\n"     \
+    "v_max_f32_dpp %5, %5, %5 " ctl " row_mask:0xf bank_mask:0xf\n"
+    lx = x; hx = x; ly = y; hy = y; lz = z; hz = z;
+    asm volatile("s_nop 1\n" EPNET_ROWBOX_STEP("quad_perm:[1,0,3,2]") EPNET_ROWBOX_STEP("quad_perm:[2,3,0,1]")
+                 EPNET_ROWBOX_STEP("row_ror:4") EPNET_ROWBOX_STEP("row_ror:8") "s_nop 1"
+                 : "+v"(lx), "+v"(hx), "+v"(ly), "+v"(hy), "+v"(lz), "+v"(hz));
+#undef EPNET_ROWBOX_STEP
+}
+
 }  // namespace epnet

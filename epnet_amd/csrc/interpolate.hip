@@ -15,6 +15,7 @@
 // three_interpolate: out = w0*p[i0] + w1*p[i1] + w2*p[i2], left to right, no contraction (:96).
 // A thread owns 4 consecutive unknowns, keeps their 12 indices and weights in registers and
 // loops over a chunk of channels (the reference re-reads idx and weight for every channel).
+#include <limits.h>
 #include <math.h>
 #include <stdlib.h>
 
@@ -261,7 +262,9 @@ __global__ __launch_bounds__(kNnTileThreads) void three_nn_tile_kernel(int n, in
                                                                        const float *__restrict__ boxes_k,
                                                                        float *__restrict__ dist2, int *__restrict__ idx) {
     extern __shared__ float s_boxes[];                  // the known buckets' boxes, shared by the 4 waves
-    __shared__ float4 s_pts[kNnTileThreads / 64][64];   // the known bucket a wave is scanning
+    // the known bucket a wave is scanning, one array per component (x[64] y[64] z[64] k[64]): four consecutive points' x (y, z)
+    // arrive as one 16-byte broadcast read, already paired for the packed arithmetic
+    __shared__ float4 s_pts[kNnTileThreads / 64][4][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int bs = blockIdx.y;
     const int ub = blockIdx.x * (kNnTileThreads / 64) + wave;
@@ -278,58 +281,64 @@ __global__ __launch_bounds__(kNnTileThreads) void three_nn_tile_kernel(int n, in
     const bool valid = ku >= 0;
     if (!__ballot(valid)) return;  // a bucket of padding
     constexpr unsigned kNone = 0xFFFFFFFFu;
-    float4 *pts = s_pts[wave];
-
-    unsigned d0 = kNone, d1 = kNone, d2 = kNone;
-    int i0 = 0x7fffffff, i1 = 0x7fffffff, i2 = 0x7fffffff;
+    // The three best (d, k) pairs of this lane's unknown as 64-bit keys bits(d) << 32 | (k ^ 0x80000000): d >= +0, so the unsigned
+    // order of the keys is the lexicographic (d, k) order. An empty slot is (+inf, INT_MIN): the reference's lists start at
+    // (float)1e40 = +inf and take a point only if d < best (interpolate_gpu.cu:30-48), so a distance of +inf (padding rows carry
+    // 3e38 coordinates: their d overflows) or NaN (bits above +inf's in the unsigned order) never enters -- with this start value
+    // the plain key comparison below says exactly that, and the distance bits need no validity mask at all.
+    constexpr unsigned kInf = 0x7F800000u;
+    typedef unsigned long long u64;
+    u64 e0 = (u64)kInf << 32, e1 = e0, e2 = e0;
+#define d2 ((unsigned)(e2 >> 32))
+    float *const px_ = reinterpret_cast<float *>(s_pts[wave][0]);
+    const float4 *const qx = s_pts[wave][0], *const qy = s_pts[wave][1], *const qz = s_pts[wave][2];
+    const int4 *const qk = reinterpret_cast<const int4 *>(s_pts[wave][3]);
     // four known points at a time: the squared distances two to an instruction (v_pk_add_f32 / v_pk_mul_f32 round like the
     // scalar forms: same (dx*dx + dy*dy) + dz*dz), one vote for the four, then the insertions of those that matter
     typedef float f2 __attribute__((ext_vector_type(2)));
     const f2 ux2 = {u.x, u.x}, uy2 = {u.y, u.y}, uz2 = {u.z, u.z};
     auto insert = [&](unsigned db, int k) {
-        const bool lt2 = db < d2 || (db == d2 && k < i2);
-        if (!__ballot(lt2 && db != kNone)) return;  // nobody's list changes
-        const bool lt0 = db < d0 || (db == d0 && k < i0), lt1 = db < d1 || (db == d1 && k < i1);
-        if (db != kNone) {
-            d2 = lt1 ? d1 : (lt2 ? db : d2);  i2 = lt1 ? i1 : (lt2 ? k : i2);
-            d1 = lt0 ? d0 : (lt1 ? db : d1);  i1 = lt0 ? i0 : (lt1 ? k : i1);
-            d0 = lt0 ? db : d0;               i0 = lt0 ? k : i0;
-        }
+        const u64 e = ((u64)db << 32) | ((unsigned)k ^ 0x80000000u);
+        const bool lt2 = e < e2;
+        if (!__ballot(lt2)) return;  // nobody's list changes
+        const bool lt0 = e < e0, lt1 = e < e1;
+        e2 = lt1 ? e1 : (lt2 ? e : e2);
+        e1 = lt0 ? e0 : (lt1 ? e : e1);
+        e0 = lt0 ? e : e0;
     };
-    auto offer4 = [&](const float4 p0, const float4 p1, const float4 p2, const float4 p3) {
-        const f2 ax = {p0.x, p1.x}, ay = {p0.y, p1.y}, az = {p0.z, p1.z};
-        const f2 bx = {p2.x, p3.x}, by = {p2.y, p3.y}, bz = {p2.z, p3.z};
+    auto offer4 = [&](int q) {  // points 4q .. 4q+3 of the staged bucket
+        const float4 X = qx[q], Y = qy[q], Z = qz[q];
+        const f2 ax = {X.x, X.y}, ay = {Y.x, Y.y}, az = {Z.x, Z.y};
+        const f2 bx = {X.z, X.w}, by = {Y.z, Y.w}, bz = {Z.z, Z.w};
         const f2 adx = ux2 - ax, ady = uy2 - ay, adz = uz2 - az;
         const f2 bdx = ux2 - bx, bdy = uy2 - by, bdz = uz2 - bz;
         const f2 da = adx * adx + ady * ady + adz * adz;
         const f2 dbv = bdx * bdx + bdy * bdy + bdz * bdz;
-        const int k0 = __float_as_int(p0.w), k1 = __float_as_int(p1.w), k2 = __float_as_int(p2.w), k3 = __float_as_int(p3.w);
-        // padding rows and non-finite distances never enter a list, as in the reference (interpolate_gpu.cu:37-48)
-        const float inf = __builtin_huge_valf();
-        const unsigned b0 = (k0 >= 0 && da.x < inf) ? __float_as_uint(da.x) : kNone;
-        const unsigned b1 = (k1 >= 0 && da.y < inf) ? __float_as_uint(da.y) : kNone;
-        const unsigned b2 = (k2 >= 0 && dbv.x < inf) ? __float_as_uint(dbv.x) : kNone;
-        const unsigned b3 = (k3 >= 0 && dbv.y < inf) ? __float_as_uint(dbv.y) : kNone;
+        const unsigned b0 = __float_as_uint(da.x), b1 = __float_as_uint(da.y), b2 = __float_as_uint(dbv.x), b3 = __float_as_uint(dbv.y);
         // (ties with the third entry are rare: a conservative '<=' on the distance alone keeps the vote cheap)
         const unsigned nearest = min(min(b0, b1), min(b2, b3));
-        if (!__ballot(nearest <= d2 && nearest != kNone)) return;
-        insert(b0, k0);
-        insert(b1, k1);
-        insert(b2, k2);
-        insert(b3, k3);
+        if (!__ballot(nearest <= d2)) return;
+        const int4 K = qk[q];
+        insert(b0, K.x);
+        insert(b1, K.y);
+        insert(b2, K.z);
+        insert(b3, K.w);
     };
     // A known bucket covers a 4x larger region than a bucket of unknowns (the known set is the 4x sparser FPS subset), so most of
     // its 64 points are out of reach even when the bucket's box is not: the box of each ROW of 16 consecutive points (compact:
     // the points are in spatial order) is found on the fly with four DPP steps per coordinate, and a row is offered only if
-    // some lane's exact lower bound to that box is within its third distance (three_nn of a 256-scene step 1.5 -> ... ms)
+    // some lane's exact lower bound to that box is within its third distance
     auto scan = [&](int kb) {
         const float4 kp = sorted_k[((size_t)kb << 6) + lane];  // one coalesced row, then broadcast reads out of LDS
         __builtin_amdgcn_wave_barrier();
-        pts[lane] = kp;
+        px_[lane] = kp.x;
+        px_[64 + lane] = kp.y;
+        px_[128 + lane] = kp.z;
+        px_[192 + lane] = kp.w;
         __builtin_amdgcn_wave_barrier();
         // padding rows carry 3e38: they only widen a row's box (never a wrong skip); non-finite points are never offered
-        const float rlx = row16_minf(kp.x), rhx = row16_maxf(kp.x), rly = row16_minf(kp.y), rhy = row16_maxf(kp.y),
-                    rlz = row16_minf(kp.z), rhz = row16_maxf(kp.z);
+        float rlx, rhx, rly, rhy, rlz, rhz;
+        row16_boxes(kp.x, kp.y, kp.z, rlx, rhx, rly, rhy, rlz, rhz);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float blx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rlx), r * 16));
@@ -342,13 +351,10 @@ __global__ __launch_bounds__(kNnTileThreads) void three_nn_tile_kernel(int n, in
                         pz = __builtin_amdgcn_fmed3f(u.z, blz, bhz);
             const float ex = u.x - px, ey = u.y - py, ez = u.z - pz;
             const float Lf = ex * ex + ey * ey + ez * ez;  // same expression as the distance: a lower bound of every point's
-            // (a NaN bound -- non-finite coordinates -- compares false and keeps the row)
-            if (!__ballot(valid && !(Lf > __uint_as_float(d2 == kNone ? 0x7F800000u : d2)))) continue;
+            // (a NaN bound -- non-finite coordinates -- compares false and keeps the row; an empty third slot is +inf)
+            if (!__ballot(valid && !(Lf > __uint_as_float(d2)))) continue;
 #pragma unroll
-            for (int j = r * 16; j < r * 16 + 16; j += 4) {
-                const float4 p0 = pts[j], p1 = pts[j + 1], p2 = pts[j + 2], p3 = pts[j + 3];
-                offer4(p0, p1, p2, p3);
-            }
+            for (int q = r * 4; q < r * 4 + 4; ++q) offer4(q);
         }
     };
 
@@ -364,7 +370,7 @@ __global__ __launch_bounds__(kNnTileThreads) void three_nn_tile_kernel(int n, in
         const float g2 = gx * gx + gy * gy + gz * gz;
         return (bx[0] < 3.0e38f && g2 < __builtin_huge_valf()) ? __float_as_uint(g2) : kNone;
     };
-    // does any lane still need known bucket kb?  (d2 == kNone: its list is not full yet)
+    // does any lane still need known bucket kb?  (d2 == +inf: its list is not full yet)
     auto wanted = [&](int kb) -> bool {
         const float *bx = s_boxes + kb * 6;  // wave-uniform: broadcast reads
         const float px = __builtin_amdgcn_fmed3f(u.x, bx[0], bx[1]), py = __builtin_amdgcn_fmed3f(u.y, bx[2], bx[3]),
@@ -408,13 +414,15 @@ __global__ __launch_bounds__(kNnTileThreads) void three_nn_tile_kernel(int n, in
         float *dd = dist2 + ((size_t)bs * n + ku) * 3;
         int *ii = idx + ((size_t)bs * n + ku) * 3;
         // unfilled slot: (float)1e40 = inf, index 0 (interpolate_gpu.cu:30-31)
-        dd[0] = d0 != kNone ? __uint_as_float(d0) : __builtin_huge_valf();
-        dd[1] = d1 != kNone ? __uint_as_float(d1) : __builtin_huge_valf();
-        dd[2] = d2 != kNone ? __uint_as_float(d2) : __builtin_huge_valf();
-        ii[0] = d0 != kNone ? i0 : 0;
-        ii[1] = d1 != kNone ? i1 : 0;
-        ii[2] = d2 != kNone ? i2 : 0;
+        const u64 es[3] = {e0, e1, e2};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const unsigned d = (unsigned)(es[r] >> 32);
+            dd[r] = __uint_as_float(d);
+            ii[r] = d != kInf ? (int)((unsigned)es[r] ^ 0x80000000u) : 0;
+        }
     }
+#undef d2
 }
 
 constexpr int kTiThreads = 256;

@@ -115,6 +115,10 @@ class SAStack:
         # levels 2.. of the pyramid sample the centres of the level above: with the chain of tie-free round counts handed from level
         # to level (epnet_sample_centres_chain) their rounds are skipped wherever the answer is known to be 0 .. m-1
         self.chain = bool(int(os.environ.get("EPNET_SA_CHAIN", "1"))) and fused_sampling
+        # the level-1 sampling issued ahead of stage G's first kernel (both wait for the level-1 index only): its one-per-CU workgroups
+        # find their registers before the wide kernels fill the CUs. 128 scenes 2.62 -> 2.57 ms, 256 scenes with every query in
+        # stage G 3.52 -> 3.43; nothing once stage G starts with an LDS-staged gather (queries of level 2 in stage S: 3.21 = 3.22)
+        self.s_first = bool(int(os.environ.get("EPNET_SA_S_FIRST", "0" if self.s_query_levels else "1")))
         self.tail_scales = int(os.environ.get("EPNET_SA_TAIL_SCALES", "0"))
         self.multi_query = bool(int(os.environ.get("EPNET_SA_MULTI_QUERY", "1")))  # both scales of a level in one launch
         self.multi_group = bool(int(os.environ.get("EPNET_SA_MULTI_GROUP", "1")))  # both groupings of a level in one call
@@ -287,7 +291,12 @@ class SAStack:
             # built before stage G is issued: a one-workgroup-per-scene kernel with 64 KB of LDS cannot find a free
             # CU once the wide stage-G kernels are in flight
             ext.scene_index_build_wrapper(self.batch, first["n"], xyz, first["sets"][parity]["index"])
-        side.wait_stream(main)
+        forked = torch.cuda.Event()
+        forked.record(main)
+        s_cur = xyz
+        if self.s_first:   # the level-1 sampling is issued before the first kernel of stage G (which depends on the index build only)
+            s_cur = self._sample_level(first, xyz, parity, index_built=True)
+        side.wait_event(forked)
         with torch.cuda.stream(side):
             # order inside stage G: everything of the previous batch's stage S is complete, so only "ball query
             # before its grouping" binds. The level-1 FPS of stage S holds ~80 % of every CU's vector registers
@@ -316,9 +325,8 @@ class SAStack:
                     self._group_scale(first, S, prev_xyz, 1 - parity)
             if self.with_fp:
                 self._interpolate_fp(1 - parity)
-        cur = xyz
-        for L in self.levels:
-            cur = self._sample_level(L, cur, parity, index_built=L is first)
+        for L in self.levels[(1 if self.s_first else 0):]:
+            s_cur = self._sample_level(L, s_cur, parity, index_built=L is first)
         if self.with_fp:
             self._search_fp(xyz, parity)
         if self.s_query_levels:
