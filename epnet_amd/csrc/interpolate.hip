@@ -247,11 +247,19 @@ __global__ __launch_bounds__(kNnIxThreads) void three_nn_indexed_kernel(int n, i
 //   2. for a known bucket K each lane evaluates the lower bound L = |clamp(u, box_K) - u|^2 (same fp32
 //      expression as the distance); K is scanned -- by the whole wave -- if ANY lane has L <= its d3; the walk
 //      stops when the smallest remaining gap (a lower bound of every lane's L) exceeds every lane's d3.
-// A scan walks the bucket's 64 known points as wave-uniform (scalar) loads; every lane keeps its own three best
+// A scan walks the bucket's 64 known points through wave-uniform addresses (scalar loads: the coordinates arrive in SGPRs and feed
+// the packed arithmetic directly, no LDS staging); every lane keeps its own three best
 // under the lexicographic (d, k) order, so there is no cross-lane merge at all. A bucket that is not scanned has
 // L > d3 for every lane: it holds neither a closer point nor an equal one with a smaller index -- the result is
 // the reference's, bit for bit. ~2x fewer instructions per unknown than the wave-per-unknown kernel above.
 constexpr int kNnTileThreads = 256;
+
+#ifdef EPNET_NN_STATS  // diagnostic build only (profiles/micro/nn_stats.py): per-wave work counters of the tile kernel
+__device__ unsigned long long g_nn_stats[16];
+#define EPNET_NN_CNT(slot, v) nn_acc[slot] += (unsigned long long)(v)
+#else
+#define EPNET_NN_CNT(slot, v)
+#endif
 
 constexpr int kNnTileMaxBoxes = 1024;  // known-bucket boxes staged in LDS (24 KB): m <= 65536
 
@@ -262,9 +270,6 @@ __global__ __launch_bounds__(kNnTileThreads) void three_nn_tile_kernel(int n, in
                                                                        const float *__restrict__ boxes_k,
                                                                        float *__restrict__ dist2, int *__restrict__ idx) {
     extern __shared__ float s_boxes[];                  // the known buckets' boxes, shared by the 4 waves
-    // the known bucket a wave is scanning, one array per component (x[64] y[64] z[64] k[64]): four consecutive points' x (y, z)
-    // arrive as one 16-byte broadcast read, already paired for the packed arithmetic
-    __shared__ float4 s_pts[kNnTileThreads / 64][4][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int bs = blockIdx.y;
     const int ub = blockIdx.x * (kNnTileThreads / 64) + wave;
@@ -281,6 +286,9 @@ __global__ __launch_bounds__(kNnTileThreads) void three_nn_tile_kernel(int n, in
     const bool valid = ku >= 0;
     if (!__ballot(valid)) return;  // a bucket of padding
     constexpr unsigned kNone = 0xFFFFFFFFu;
+#ifdef EPNET_NN_STATS
+    unsigned long long nn_acc[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+#endif
     // The three best (d, k) pairs of this lane's unknown as 64-bit keys bits(d) << 32 | (k ^ 0x80000000): d >= +0, so the unsigned
     // order of the keys is the lexicographic (d, k) order. An empty slot is (+inf, INT_MIN): the reference's lists start at
     // (float)1e40 = +inf and take a point only if d < best (interpolate_gpu.cu:30-48), so a distance of +inf (padding rows carry
@@ -290,9 +298,6 @@ __global__ __launch_bounds__(kNnTileThreads) void three_nn_tile_kernel(int n, in
     typedef unsigned long long u64;
     u64 e0 = (u64)kInf << 32, e1 = e0, e2 = e0;
 #define d2 ((unsigned)(e2 >> 32))
-    float *const px_ = reinterpret_cast<float *>(s_pts[wave][0]);
-    const float4 *const qx = s_pts[wave][0], *const qy = s_pts[wave][1], *const qz = s_pts[wave][2];
-    const int4 *const qk = reinterpret_cast<const int4 *>(s_pts[wave][3]);
     // four known points at a time: the squared distances two to an instruction (v_pk_add_f32 / v_pk_mul_f32 round like the
     // scalar forms: same (dx*dx + dy*dy) + dz*dz), one vote for the four, then the insertions of those that matter
     typedef float f2 __attribute__((ext_vector_type(2)));
@@ -301,15 +306,16 @@ __global__ __launch_bounds__(kNnTileThreads) void three_nn_tile_kernel(int n, in
         const u64 e = ((u64)db << 32) | ((unsigned)k ^ 0x80000000u);
         const bool lt2 = e < e2;
         if (!__ballot(lt2)) return;  // nobody's list changes
+        EPNET_NN_CNT(5, 1);
         const bool lt0 = e < e0, lt1 = e < e1;
         e2 = lt1 ? e1 : (lt2 ? e : e2);
         e1 = lt0 ? e0 : (lt1 ? e : e1);
         e0 = lt0 ? e : e0;
     };
-    auto offer4 = [&](int q) {  // points 4q .. 4q+3 of the staged bucket
-        const float4 X = qx[q], Y = qy[q], Z = qz[q];
-        const f2 ax = {X.x, X.y}, ay = {Y.x, Y.y}, az = {Z.x, Z.y};
-        const f2 bx = {X.z, X.w}, by = {Y.z, Y.w}, bz = {Z.z, Z.w};
+    auto offer4 = [&](const float4 *__restrict__ kp4) {  // four consecutive points of a known bucket, wave-uniform address: scalar loads
+        const float4 P0 = kp4[0], P1 = kp4[1], P2 = kp4[2], P3 = kp4[3];
+        const f2 ax = {P0.x, P1.x}, ay = {P0.y, P1.y}, az = {P0.z, P1.z};
+        const f2 bx = {P2.x, P3.x}, by = {P2.y, P3.y}, bz = {P2.z, P3.z};
         const f2 adx = ux2 - ax, ady = uy2 - ay, adz = uz2 - az;
         const f2 bdx = ux2 - bx, bdy = uy2 - by, bdz = uz2 - bz;
         const f2 da = adx * adx + ady * ady + adz * adz;
@@ -317,25 +323,22 @@ __global__ __launch_bounds__(kNnTileThreads) void three_nn_tile_kernel(int n, in
         const unsigned b0 = __float_as_uint(da.x), b1 = __float_as_uint(da.y), b2 = __float_as_uint(dbv.x), b3 = __float_as_uint(dbv.y);
         // (ties with the third entry are rare: a conservative '<=' on the distance alone keeps the vote cheap)
         const unsigned nearest = min(min(b0, b1), min(b2, b3));
+        EPNET_NN_CNT(3, 1);
         if (!__ballot(nearest <= d2)) return;
-        const int4 K = qk[q];
-        insert(b0, K.x);
-        insert(b1, K.y);
-        insert(b2, K.z);
-        insert(b3, K.w);
+        EPNET_NN_CNT(4, 1);
+        insert(b0, __float_as_int(P0.w));
+        insert(b1, __float_as_int(P1.w));
+        insert(b2, __float_as_int(P2.w));
+        insert(b3, __float_as_int(P3.w));
     };
     // A known bucket covers a 4x larger region than a bucket of unknowns (the known set is the 4x sparser FPS subset), so most of
     // its 64 points are out of reach even when the bucket's box is not: the box of each ROW of 16 consecutive points (compact:
     // the points are in spatial order) is found on the fly with four DPP steps per coordinate, and a row is offered only if
     // some lane's exact lower bound to that box is within its third distance
     auto scan = [&](int kb) {
-        const float4 kp = sorted_k[((size_t)kb << 6) + lane];  // one coalesced row, then broadcast reads out of LDS
-        __builtin_amdgcn_wave_barrier();
-        px_[lane] = kp.x;
-        px_[64 + lane] = kp.y;
-        px_[128 + lane] = kp.z;
-        px_[192 + lane] = kp.w;
-        __builtin_amdgcn_wave_barrier();
+        const float4 *__restrict__ const bucket = sorted_k + ((size_t)kb << 6);
+        const float4 kp = bucket[lane];  // one point per lane: the row boxes
+        EPNET_NN_CNT(2, 1);
         // padding rows carry 3e38: they only widen a row's box (never a wrong skip); non-finite points are never offered
         float rlx, rhx, rly, rhy, rlz, rhz;
         row16_boxes(kp.x, kp.y, kp.z, rlx, rhx, rly, rhy, rlz, rhz);
@@ -354,7 +357,7 @@ __global__ __launch_bounds__(kNnTileThreads) void three_nn_tile_kernel(int n, in
             // (a NaN bound -- non-finite coordinates -- compares false and keeps the row; an empty third slot is +inf)
             if (!__ballot(valid && !(Lf > __uint_as_float(d2)))) continue;
 #pragma unroll
-            for (int q = r * 4; q < r * 4 + 4; ++q) offer4(q);
+            for (int q = r * 4; q < r * 4 + 4; ++q) offer4(bucket + q * 4);
         }
     };
 
@@ -389,6 +392,7 @@ __global__ __launch_bounds__(kNnTileThreads) void three_nn_tile_kernel(int n, in
             if (mn == kNone || !__ballot(valid && mn <= d2)) break;
             const int kb = (int)__builtin_ctzll(__ballot(g == mn));
             if (lane == kb) g = kNone;
+            EPNET_NN_CNT(1, 1);
             if (wanted(kb)) scan(kb);
         }
     } else {
@@ -422,8 +426,25 @@ __global__ __launch_bounds__(kNnTileThreads) void three_nn_tile_kernel(int n, in
             ii[r] = d != kInf ? (int)((unsigned)es[r] ^ 0x80000000u) : 0;
         }
     }
+#ifdef EPNET_NN_STATS
+    if (lane == 0) {
+        for (int s_ = 0; s_ < 6; ++s_) atomicAdd(&g_nn_stats[s_], nn_acc[s_]);
+        atomicMax(&g_nn_stats[6], nn_acc[2]);                 // most buckets scanned by one wave
+        atomicAdd(&g_nn_stats[7], nn_acc[2] * nn_acc[2]);
+        atomicAdd(&g_nn_stats[8 + (nn_acc[2] >= 28 ? 7 : nn_acc[2] / 4)], 1ull);   // histogram of scans per wave, bins of 4
+    }
+#endif
 #undef d2
 }
+
+#ifdef EPNET_NN_STATS
+extern "C" int epnet_debug_nn_stats(unsigned long long *host16) {
+    hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_nn_stats), sizeof(unsigned long long) * 16);
+    unsigned long long zero[16] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_nn_stats), zero, sizeof(zero));
+    return 0;
+}
+#endif
 
 constexpr int kTiThreads = 256;
 constexpr int kTiChan = 16;

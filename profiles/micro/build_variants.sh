@@ -2,7 +2,7 @@
 set -e
 cd /root/repo/epnet_amd/csrc
 mkdir -p ../../scratch/libs
-F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -I../../include"
+F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -mllvm -amdgpu-atomic-optimizer-strategy=None -I../../include -I."
 i=0
 while [ $# -gt 0 ]; do
   name=$1; flags=$2; shift 2
