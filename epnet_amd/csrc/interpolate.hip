@@ -437,11 +437,20 @@ __global__ __launch_bounds__(kNnTileThreads) void three_nn_tile_kernel(int n, in
 #undef d2
 }
 
+#ifdef EPNET_RUNSUM_STATS
+extern "C" int epnet_debug_runsum_stats(unsigned long long *host16) {
+    (void)hipMemcpyFromSymbol(host16, HIP_SYMBOL(runsum::g_runsum_stats), sizeof(unsigned long long) * 16);
+    unsigned long long zero[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(runsum::g_runsum_stats), zero, sizeof(zero));
+    return 0;
+}
+#endif
+
 #ifdef EPNET_NN_STATS
 extern "C" int epnet_debug_nn_stats(unsigned long long *host16) {
-    hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_nn_stats), sizeof(unsigned long long) * 16);
+    (void)hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_nn_stats), sizeof(unsigned long long) * 16);
     unsigned long long zero[16] = {0};
-    hipMemcpyToSymbol(HIP_SYMBOL(g_nn_stats), zero, sizeof(zero));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_nn_stats), zero, sizeof(zero));
     return 0;
 }
 #endif

@@ -11,10 +11,11 @@
 //                   [q * ept, (q + 1) * ept) and still reads them with coalesced 16-byte loads.
 //   scatter_kernel  one 1024-thread workgroup walks a sequence of channel-row groups of one scene. Per group: the R rows of
 //                   grad_out are copied into LDS (16-byte loads, each element read from HBM once; the NEXT group's rows are
-//                   already on their way into registers while this group is summed), every thread sums its ept entries
+//                   requested as soon as this group's entry loads are out), every thread sums its ept entries
 //                   in sorted order -- closed runs go to the LDS copy of the output row with plain stores, a run that
 //                   crosses thread boundaries is finished by the thread it starts in (partial sums handed over through
-//                   LDS) -- and the output rows are added to grad_points with coalesced 16-byte accesses.
+//                   LDS) -- and the output rows are added to grad_points with coalesced 16-byte accesses. The entry words
+//                   travel a few groups ahead of the sums in a register ring (unconditional loads: countable).
 // Every thread does the same amount of work whatever the list lengths are (ball-query padding repeats an index up to
 // nsample times, FPS-subset points near the sensor are nearest to hundreds of unknowns), no list is walked through a
 // chain of dependent loads, and nothing is atomic. The order of the terms inside a run is whatever the counting sort
@@ -27,6 +28,21 @@
 
 namespace epnet {
 namespace runsum {
+
+#ifdef EPNET_RUNSUM_STATS  // diagnostic build only (profiles/micro/runsum_stats.py): phase cycle counters of the scatter kernel
+__device__ unsigned long long g_runsum_stats[16];   // [0..7]: wave 0 of every workgroup, [8..15]: its last wave
+#define EPNET_RS_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define EPNET_RS_ACC(slot, a, b) rs_acc[slot] += (unsigned long long)((b) - (a))
+#define EPNET_RS_BEGIN unsigned long long rs_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define EPNET_RS_END                                                                                     \
+    if ((threadIdx.x & 63) == 0 && (threadIdx.x == 0 || threadIdx.x == kThreads - 64))                    \
+        for (int s_ = 0; s_ < 8; ++s_) atomicAdd(&g_runsum_stats[(threadIdx.x ? 8 : 0) + s_], rs_acc[s_])
+#else
+#define EPNET_RS_STAMP(var)
+#define EPNET_RS_ACC(slot, a, b)
+#define EPNET_RS_BEGIN
+#define EPNET_RS_END
+#endif
 
 constexpr int kThreads = 1024;
 constexpr int kChunk = kThreads * 4;      // the entry array is padded to whole 16-byte loads of the workgroup
@@ -47,7 +63,7 @@ __host__ __device__ inline int slot_to_mem(int s, int ept) {
 // the longest tile whose single row fits beside the output row of n targets and the hand-over slots.
 inline int tile_floats(int n, int div, long long row_floats) {
     const long long n_pad = (n + 1 + 3) / 4 * 4;
-    long long t = ((long long)kLdsLimit / 4 - n_pad - kThreads);
+    long long t = ((long long)kLdsLimit / 4 - n_pad - 2 * kThreads);
     if (t > kMaxRowFloats) t = kMaxRowFloats;
     if (t * div > kMaxEntries) t = kMaxEntries / div;
     if (const char *e = getenv("EPNET_RUNSUM_TILE")) {  // tuning: shorter tiles, more workgroups per CU
@@ -65,7 +81,7 @@ inline bool usable(int n, int div, long long entries, long long row_floats) {
 
 inline size_t lds_bytes(int rows, int n, int row_floats) {
     const int n_pad = (n + 1 + 3) / 4 * 4;
-    return ((size_t)rows * row_floats + (size_t)rows * n_pad + (size_t)rows * kThreads) * sizeof(float);
+    return ((size_t)rows * row_floats + (size_t)rows * n_pad + (size_t)2 * rows * kThreads) * sizeof(float);
 }
 
 // rows per pass: as many as fit (the entry words are read once per pass), but not so many that the chip runs short of
@@ -165,7 +181,7 @@ __global__ __launch_bounds__(kThreads) void pack_kernel(int n, int p, int div, s
 // grid (workgroups per scene, b); workgroup x takes the row groups [x * per_wg, (x + 1) * per_wg) of its scene.
 // grad_out rows of a scene: row_floats floats at grad_out + bs * gstride + row * row_stride (row_stride > row_floats: one tile
 // of longer rows); grad_points rows: ((bs * c) + row) * n.
-template <int R, bool W>
+template <int R, bool W, int kPre = 8>   // kPre: 16-byte loads per thread that bring in the R rows (R * row_floats <= kPre * 4096)
 __global__ __launch_bounds__(kThreads) void scatter_kernel(int c, int n, int row_floats, int row_stride, int P, int per_wg, int vec_out,
                                                            size_t gstride,
                                                            const float *__restrict__ grad_out,
@@ -174,16 +190,29 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(int c, int n, int row
                                                            float *__restrict__ grad_points) {
     extern __shared__ float s_mem[];
     __shared__ unsigned char s_whole[kThreads];
-    const int q = threadIdx.x, bs = blockIdx.y;
+    const int q = threadIdx.x;
+    // Workgroups are dealt round-robin over the 8 XCDs (linear id % 8), each with its own L2. Every row pass of a workgroup re-reads
+    // the scene's sorted entries (up to 0.4 MB): the workgroups of a scene therefore go to ONE XCD (a bijective relabelling of the
+    // linear id; placement is a matter of speed only), where the entries of its two or three scenes stay in L2 instead of all
+    // scenes' entries passing through every L2.
+    int wg_x, bs;
+    {
+        const int nwg = (int)(gridDim.x * gridDim.y), orig = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+        const int xcd = orig & 7, qq = nwg >> 3, rr = nwg & 7;
+        const int wgid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3);
+        bs = wgid / (int)gridDim.x;
+        wg_x = wgid - bs * (int)gridDim.x;
+    }
     const int n_pad = (n + 1 + 3) / 4 * 4;
     float *s_row = s_mem;                           // R rows of grad_out
     float *s_out = s_row + (size_t)R * row_floats;  // R output rows (+ the dump slot n)
     float *s_first = s_out + (size_t)R * n_pad;     // partial sum of the run a thread's range starts inside of
+    float *s_dump = s_first + (size_t)R * kThreads; // a private word per thread and row: where the running sums that nobody reads go
     const int ept = P / kThreads, nq = ept >> 2;
     const uint4 *ent4 = reinterpret_cast<const uint4 *>(ent + (size_t)bs * P);
     const float4 *w4p = W ? reinterpret_cast<const float4 *>(wsorted + (size_t)bs * P) : nullptr;
     const int groups = (c + R - 1) / R;
-    const int g_beg = blockIdx.x * per_wg, g_end = min(groups, g_beg + per_wg);
+    const int g_beg = wg_x * per_wg, g_end = min(groups, g_beg + per_wg);
     if (g_beg >= g_end) return;
 
     // what a thread needs to know about its slice of the sorted entries, the same for every row
@@ -227,7 +256,6 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(int c, int n, int row
     const float *go = grad_out + (size_t)bs * gstride;
     float *gp = grad_points + (size_t)bs * c * n;
     const int row4 = row_floats >> 2;
-    constexpr int kPre = 8;  // R * row_floats <= 32768 floats = 8 x 16 bytes per thread
     typedef float f4 __attribute__((ext_vector_type(4)));
     f4 pre[kPre];
     auto fetch = [&](int g) {
@@ -245,9 +273,20 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(int c, int n, int row
             }
         }
     };
+    constexpr int kAhead = R == 1 ? 3 : (R == 2 ? 2 : 1);  // (the wider variants have no registers to spare)
+    uint4 ering[kAhead];
+    float4 wring[W ? kAhead : 1];
+    auto load_group = [&](int slot, int gi) {
+        ering[slot] = ent4[gi * kThreads + q];
+        if (W) wring[slot] = w4p[gi * kThreads + q];
+    };
+#pragma unroll
+    for (int j = 0; j < kAhead; ++j) load_group(j, min(j, nq - 1));
     fetch(g_beg);
+    EPNET_RS_BEGIN;
     for (int g = g_beg; g < g_end; ++g) {
         const int c0 = g * R, nr = min(R, c - c0);
+        EPNET_RS_STAMP(t_a);
         {
             const int total4 = nr * row4;
             f4 *dst = reinterpret_cast<f4 *>(s_row);
@@ -257,32 +296,29 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(int c, int n, int row
                 if (e < total4) dst[e] = pre[k];
             }
         }
-        if (g + 1 < g_end) fetch(g + 1);  // in flight while this group is summed
         __syncthreads();
+        EPNET_RS_STAMP(t_b);
         // the rows of grad_points this thread will add to, requested before the sums so that the read-modify-write at the
         // end does not wait for them
         const int n4 = n >> 2;
         const bool have_old = vec_out && q < nr * n4;
         float4 oldv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (have_old) oldv = reinterpret_cast<const float4 *>(gp + (size_t)(c0 + q / n4) * n)[q - (q / n4) * n4];
-        // Branch-free walk over the thread's entries: EVERY entry stores the running sum of its run -- to the output row
-        // slot of its target, or, while the thread is still inside the run its range began in, to the hand-over slot; a later
-        // entry of the same run overwrites the slot with the more complete sum, so after the last entry the slot holds the
-        // run's sum over this thread's range. (A run's slot in s_out is written by one thread only: the one it starts in.)
+        // Branch-free walk over the thread's entries: EVERY entry stores the running sum of its run -- the last entry of a run
+        // (and the thread's last entry, whose run the next thread may continue) to the output row slot of its target, an entry
+        // inside the run the thread's range began in to the hand-over slot, every other entry to the thread's private dump
+        // word. (Neighbouring lanes hold neighbouring targets, a few words apart: with every running sum going to its target's
+        // slot the stores of a wave met in a quarter of the banks, 4 to 8 lanes deep, and set the pace of the whole kernel; the
+        // private words of a wave are consecutive.) A run's slot in s_out is written by one thread only: the one it starts in.
         float acc[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = 0.f;
         bool first_open = open_start;
-        uint4 e4 = ent4[q];
-        float4 w4 = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (W) w4 = w4p[q];
-        for (int gi = 0; gi < nq; ++gi) {
-            uint4 en = e4;
-            float4 wn = w4;
-            if (gi + 1 < nq) {  // the next four entries are on their way while these are summed
-                en = ent4[(gi + 1) * kThreads + q];
-                if (W) wn = w4p[(gi + 1) * kThreads + q];
-            }
+        // the entry words of kAhead groups of four are in flight ahead of the sums (they come from L2 at best). The ring's slots
+        // are static (the loop is unrolled by its length) and every load is UNCONDITIONAL (past the end it repeats the last
+        // group): only then can the compiler count the loads in flight and wait for exactly the group it needs -- with a
+        // conditional load it falls back to `s_waitcnt vmcnt(0)` at every use, i.e. no prefetch at all
+        auto sum_group = [&](const uint4 e4, const float4 w4, const bool last_group) __attribute__((always_inline)) {
             const unsigned es[4] = {e4.x, e4.y, e4.z, e4.w};
             const float ws[4] = {w4.x, w4.y, w4.z, w4.w};
             float v[4][R];  // all reads of the group before any store (the stores go to the same LDS array: the compiler
@@ -296,19 +332,44 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(int c, int n, int row
                 const unsigned e = es[k];
                 const int key = (int)((e >> 16) & 0x7FFFu);
                 const bool end = (int)e < 0;
-                const int slot = first_open ? (int)(s_first - s_out) + q : key;   // index relative to s_out, row 0
+                const bool real = !first_open && (end || (k == 3 && last_group));
+                // index relative to s_out, row 0
+                const int slot = real ? key : (first_open ? (int)(s_first - s_out) + q : (int)(s_dump - s_out) + q);
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     acc[r] += W ? v[k][r] * ws[k] : v[k][r];
-                    s_out[(first_open ? r * kThreads : r * n_pad) + slot] = acc[r];
+                    s_out[(real ? r * n_pad : r * kThreads) + slot] = acc[r];
                     acc[r] = end ? 0.f : acc[r];
                 }
                 first_open = first_open && !end;
             }
-            e4 = en;
-            w4 = wn;
+        };
+        int g0 = 0;
+        for (; g0 + kAhead <= nq; g0 += kAhead) {
+#pragma unroll
+            for (int j = 0; j < kAhead; ++j) {
+                const uint4 e4 = ering[j];
+                const float4 w4 = W ? wring[j] : make_float4(1.f, 1.f, 1.f, 1.f);
+                load_group(j, min(g0 + j + kAhead, nq - 1));
+                sum_group(e4, w4, g0 + j + 1 == nq);
+            }
         }
+#pragma unroll
+        for (int j = 0; j < kAhead - 1; ++j)   // the nq % kAhead groups left over (their words are in the ring's first slots)
+            if (g0 + j < nq) sum_group(ering[j], W ? wring[j] : make_float4(1.f, 1.f, 1.f, 1.f), g0 + j + 1 == nq);
+        // the first groups' words again for the next pass (the same words every pass), ahead of the rows
+#pragma unroll
+        for (int j = 0; j < kAhead; ++j) load_group(j, min(j, nq - 1));
+        // The next group's rows are requested HERE, behind the last entry loads of this pass: vector loads return in order, so a
+        // request issued ahead of the entry loop would have every wait for entry words wait for the HBM rows as well (the compiler
+        // emitted `s_waitcnt vmcnt(0)` at the head of the loop: no overlap at all). Now they travel during the hand-over steps,
+        // the output rows and the next copy into LDS. (The old output values were requested before the loop: pinned here so
+        // that nothing issued before the prefetch is waited for after it.)
+        if (have_old) asm volatile("" ::"v"(oldv.x), "v"(oldv.y), "v"(oldv.z), "v"(oldv.w));
+        if (g + 1 < g_end) fetch(g + 1);
+        EPNET_RS_STAMP(t_c);
         __syncthreads();
+        EPNET_RS_STAMP(t_d);
         if (head) {  // collect the (near) links of the run this thread's range ends inside of
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -326,6 +387,7 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(int c, int n, int row
             for (int r = 0; r < R; ++r) atomicAdd(&s_out[r * n_pad + first_key], s_first[r * kThreads + q]);
         }
         __syncthreads();
+        EPNET_RS_STAMP(t_e);
         // grad_points += the output rows; the LDS copies go back to zero for the next group
         if (vec_out) {
             for (int i = q; i < nr * n4; i += kThreads) {
@@ -343,9 +405,13 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(int c, int n, int row
                 s_out[r * n_pad + j] = 0.f;
             }
         }
+        EPNET_RS_STAMP(t_f);
+        EPNET_RS_ACC(0, t_a, t_b); EPNET_RS_ACC(1, t_b, t_c); EPNET_RS_ACC(2, t_c, t_d); EPNET_RS_ACC(3, t_d, t_e); EPNET_RS_ACC(4, t_e, t_f);
+        EPNET_RS_ACC(5, t_a, t_a + 1);
         // (the next group's rows overwrite s_row only after every thread has passed the barrier before the head step, and
         // its sums start only after the barrier that follows the copy: the zeroing above is complete by then)
     }
+    EPNET_RS_END;
 }
 
 template <bool W>
@@ -382,14 +448,17 @@ inline int launch(int b, int c, int n, int div, int row_floats, const float *gra
         const int per_wg = div_up(groups, wgs);
         wgs = div_up(groups, per_wg);
         dim3 grid(wgs, b);
-#define EPNET_RUNSUM(R_)                                                                                                     \
-    hipLaunchKernelGGL((scatter_kernel<R_, W>), grid, dim3(kThreads), lds, s, c, n, len, row_floats, P, per_wg, vec_out, gstride, \
+#define EPNET_RUNSUM(R_, PRE_)                                                                                                 \
+    hipLaunchKernelGGL((scatter_kernel<R_, W, PRE_>), grid, dim3(kThreads), lds, s, c, n, len, row_floats, P, per_wg, vec_out, gstride, \
                        grad_out + pos0, ent, wsorted, grad_points)
         switch (rows) {
-            case 8: EPNET_RUNSUM(8); break;
-            case 4: EPNET_RUNSUM(4); break;
-            case 2: EPNET_RUNSUM(2); break;
-            default: EPNET_RUNSUM(1); break;
+            case 8: EPNET_RUNSUM(8, 8); break;
+            case 4: EPNET_RUNSUM(4, 8); break;
+            case 2: EPNET_RUNSUM(2, 8); break;
+            default:
+                if (len <= 16384) EPNET_RUNSUM(1, 4);   // (frees the registers of the entry-word ring)
+                else EPNET_RUNSUM(1, 8);
+                break;
         }
 #undef EPNET_RUNSUM
         rc = check_launch(what);
