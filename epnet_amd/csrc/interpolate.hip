@@ -292,25 +292,32 @@ __global__ __launch_bounds__(kNnTileThreads) void three_nn_tile_kernel(int n, in
     // The three best (d, k) pairs of this lane's unknown as 64-bit keys bits(d) << 32 | (k ^ 0x80000000): d >= +0, so the unsigned
     // order of the keys is the lexicographic (d, k) order. An empty slot is (+inf, INT_MIN): the reference's lists start at
     // (float)1e40 = +inf and take a point only if d < best (interpolate_gpu.cu:30-48), so a distance of +inf (padding rows carry
-    // 3e38 coordinates: their d overflows) or NaN (bits above +inf's in the unsigned order) never enters -- with this start value
-    // the plain key comparison below says exactly that, and the distance bits need no validity mask at all.
+    // 3e38 coordinates: their d overflows) or NaN (bits above +inf's) never enters -- with this start value the plain key order
+    // says exactly that, and the distance bits need no validity mask at all.
+    // The keys are held and ordered AS DOUBLES: the high word is at most a float NaN's 0x7FFFFFFF, below the double exponent
+    // of all ones (0x7FF00000), so every key is a finite non-negative double (|x| is applied to the candidate: a negative float
+    // NaN becomes a positive one), and for those the order of the values is the order of the bit patterns. A sorted insertion
+    // is then five v_min_f64 / v_max_f64 (full rate, branch-free, exact; a key with d = 0 is a denormal double: the f64
+    // denormal mode of a HIP kernel is IEEE) instead of three 64-bit compares and ten selects.
     constexpr unsigned kInf = 0x7F800000u;
-    typedef unsigned long long u64;
-    u64 e0 = (u64)kInf << 32, e1 = e0, e2 = e0;
-#define d2 ((unsigned)(e2 >> 32))
+    double e0 = __hiloint2double((int)kInf, 0), e1 = e0, e2 = e0;
+#define d2 ((unsigned)__double2hiint(e2))
     // four known points at a time: the squared distances two to an instruction (v_pk_add_f32 / v_pk_mul_f32 round like the
     // scalar forms: same (dx*dx + dy*dy) + dz*dz), one vote for the four, then the insertions of those that matter
     typedef float f2 __attribute__((ext_vector_type(2)));
     const f2 ux2 = {u.x, u.x}, uy2 = {u.y, u.y}, uz2 = {u.z, u.z};
     auto insert = [&](unsigned db, int k) {
-        const u64 e = ((u64)db << 32) | ((unsigned)k ^ 0x80000000u);
-        const bool lt2 = e < e2;
-        if (!__ballot(lt2)) return;  // nobody's list changes
+        const double e = __hiloint2double((int)db, (int)((unsigned)k ^ 0x80000000u));
+        double t0, r0, t1, r1, t2;  // (inline asm: through fmin / fmax the compiler adds a canonicalising v_max_f64 x,x per operand)
+        asm("v_min_f64 %0, |%1|, %2" : "=v"(t0) : "v"(e), "v"(e0));
+        asm("v_max_f64 %0, |%1|, %2" : "=v"(r0) : "v"(e), "v"(e0));
+        asm("v_min_f64 %0, %1, %2" : "=v"(t1) : "v"(r0), "v"(e1));
+        asm("v_max_f64 %0, %1, %2" : "=v"(r1) : "v"(r0), "v"(e1));
+        asm("v_min_f64 %0, %1, %2" : "=v"(t2) : "v"(r1), "v"(e2));
+        e0 = t0;
+        e1 = t1;
+        e2 = t2;
         EPNET_NN_CNT(5, 1);
-        const bool lt0 = e < e0, lt1 = e < e1;
-        e2 = lt1 ? e1 : (lt2 ? e : e2);
-        e1 = lt0 ? e0 : (lt1 ? e : e1);
-        e0 = lt0 ? e : e0;
     };
     auto offer4 = [&](const float4 *__restrict__ kp4) {  // four consecutive points of a known bucket, wave-uniform address: scalar loads
         const float4 P0 = kp4[0], P1 = kp4[1], P2 = kp4[2], P3 = kp4[3];
@@ -418,12 +425,12 @@ __global__ __launch_bounds__(kNnTileThreads) void three_nn_tile_kernel(int n, in
         float *dd = dist2 + ((size_t)bs * n + ku) * 3;
         int *ii = idx + ((size_t)bs * n + ku) * 3;
         // unfilled slot: (float)1e40 = inf, index 0 (interpolate_gpu.cu:30-31)
-        const u64 es[3] = {e0, e1, e2};
+        const double es[3] = {e0, e1, e2};
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            const unsigned d = (unsigned)(es[r] >> 32);
+            const unsigned d = (unsigned)__double2hiint(es[r]);
             dd[r] = __uint_as_float(d);
-            ii[r] = d != kInf ? (int)((unsigned)es[r] ^ 0x80000000u) : 0;
+            ii[r] = d != kInf ? (int)((unsigned)__double2loint(es[r]) ^ 0x80000000u) : 0;
         }
     }
 #ifdef EPNET_NN_STATS

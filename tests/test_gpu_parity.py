@@ -583,6 +583,36 @@ def test_three_nn_over_scene_indices_matches_oracle(oracle, b, n, m, kind, monke
         np.testing.assert_array_equal(host(d2), o_d2)
 
 
+@pytest.mark.parametrize("tile", [True, False])
+def test_three_nn_non_finite_coordinates(oracle, tile, monkeypatch):
+    """NaN (either sign bit) and +-inf coordinates on both sides: the reference takes a point only if `d < best` with best starting
+    at (float)1e40 = +inf (interpolate_gpu.cu:30-48), so a distance of +inf or NaN never enters a list -- unknowns with a
+    non-finite coordinate get (inf, 0) three times, known points with one are never anybody's neighbour. The bucket kernel
+    orders its (d, k) keys as doubles: a NaN of either sign must stay out of that order."""
+    from epnet_amd import pointnet2_cuda as ext
+    monkeypatch.setenv("EPNET_NN_TILE_MIN_BUCKETS", "1" if tile else "1000000000")
+    b, n, m = 2, 4096, 1536
+    unknown = rand_cloud(b, n, seed=21, kind="kitti")
+    known = rand_cloud(b, m, seed=22, kind="kitti")
+    neg_nan = np.frombuffer(np.uint32(0xFFC00000).tobytes(), dtype=np.float32)[0]
+    bad = [np.float32(np.nan), neg_nan, np.float32(np.inf), np.float32(-np.inf)]
+    rng = np.random.default_rng(5)
+    for arr, count in ((known, 40), (unknown, 60)):
+        for k in range(count):
+            arr[rng.integers(0, b), rng.integers(0, arr.shape[1]), rng.integers(0, 3)] = bad[k % 4]
+    known[1, 7] = [neg_nan, neg_nan, neg_nan]
+    unknown[0, 11] = [np.float32(np.inf), np.float32(-np.inf), neg_nan]
+    d_u, d_k = dev(unknown), dev(known)
+    o_d2, o_i = oracle.three_nn(unknown, known)
+    assert np.isinf(o_d2).any() and np.isfinite(o_d2).any()
+    ui, ki = ext.scene_index(d_u), ext.scene_index(d_k)
+    d2 = torch.full((b, n, 3), -1.0, device=DEV)
+    i = torch.full((b, n, 3), -1, dtype=torch.int32, device=DEV)
+    ext.three_nn_indexed_wrapper(b, n, m, d_u, d_k, ui, ki, d2, i)
+    np.testing.assert_array_equal(host(i), o_i)
+    np.testing.assert_array_equal(host(d2), o_d2)
+
+
 def test_scene_index_is_remembered_only_on_the_packages_own_centres():
     """a scene index is remembered on the tensor object it was built from, and only for tensors this package allocated
     itself (the centres of an SA level); a caller's tensor is indexed afresh on every call"""
