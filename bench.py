@@ -435,10 +435,17 @@ def main():
     fam = {}
     for name, head, e0, e1 in timer.records:
         label, nbytes = op_family(name, head)
-        f = fam.setdefault(label, {"ms": 0.0, "bytes": 0, "launches": 0})
-        f["ms"] += e0.elapsed_time(e1)
+        f = fam.setdefault(label, {"ms": 0.0, "bytes": 0, "launches": 0, "shapes": {}})
+        ms = e0.elapsed_time(e1)
+        f["ms"] += ms
         f["bytes"] += nbytes
         f["launches"] += 1
+        if label in ("three_nn", "three_interpolate", "group"):   # several shapes under one label: keep them apart as well
+            shape = " ".join(str(v) for v in head[:5] if isinstance(v, (int, float, list, tuple)))
+            g = f["shapes"].setdefault(shape, {"ms": 0.0, "bytes": 0, "launches": 0})
+            g["ms"] += ms
+            g["bytes"] += nbytes
+            g["launches"] += 1
     kernels = {}
     for label, f in fam.items():
         avg_ms = f["ms"] / f["launches"]
@@ -446,6 +453,11 @@ def main():
         kernels[label] = {"launches_per_step": f["launches"] // args.steps, "avg_ms": round(avg_ms, 5),
                           "step_ms": round(f["ms"] / args.steps, 5),
                           "bytes_per_launch": f["bytes"] // f["launches"], "GBps": round(gbs, 2)}
+        if f["shapes"]:
+            kernels[label]["by_shape"] = {
+                shape: {"avg_ms": round(g["ms"] / g["launches"], 5),
+                        "GBps": round(g["bytes"] / g["launches"] / (g["ms"] / g["launches"] * 1e-3) / 1e9, 2) if g["ms"] > 0 else 0.0}
+                for shape, g in f["shapes"].items()}
     def roof(label, note):
         k = kernels[label]
         traffic = pmc_traffic(label, args)

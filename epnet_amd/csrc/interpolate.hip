@@ -553,6 +553,7 @@ __global__ __launch_bounds__(kTiThreads) void three_interpolate_lds_kernel(int c
 // byte of the row-major kernel above (random 4-byte reads: two 32-lane groups over 32 banks; random 16-byte reads: four
 // 16-lane groups over 16 bank quads), which is what bounded it (3.5 TB/s against 5.2 for a plain gather).
 // rows is a multiple of 4 (c % 4 == 0), m % 4 == 0, n % 4 == 0; dynamic LDS: rows * m floats.
+template <int U>   // unknowns per thread: 4 (16-byte stores), or 1 for the coarse levels (n < 1024: a thread per unknown fills the workgroup)
 __global__ __launch_bounds__(kTiThreads) void three_interpolate_lds4_kernel(int c, int m, int n, int rows, int tile,
                                                                             const float *__restrict__ points,
                                                                             const int *__restrict__ idx,
@@ -577,11 +578,11 @@ __global__ __launch_bounds__(kTiThreads) void three_interpolate_lds4_kernel(int 
     __syncthreads();
     const int i_begin = blockIdx.x * tile, i_end = min(n, i_begin + tile);
     float *dst_base = out + ((size_t)bs * c + c0) * n;
-    for (int i0 = i_begin + threadIdx.x * 4; i0 < i_end; i0 += kTiThreads * 4) {
-        int ix[4][3];
-        float w[4][3];
+    for (int i0 = i_begin + threadIdx.x * U; i0 < i_end; i0 += kTiThreads * U) {
+        int ix[U][3];
+        float w[U][3];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 ix[u][j] = idx[((size_t)bs * n + i0 + u) * 3 + j];
@@ -590,23 +591,23 @@ __global__ __launch_bounds__(kTiThreads) void three_interpolate_lds4_kernel(int 
         const float4 *quad = s_quad;
         float *dst = dst_base + i0;
         for (int g = 0; g < groups; ++g) {
-            float4 v[4][3];
+            float4 v[U][3];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) v[u][j] = quad[ix[u][j]];
             // the reference's expression per output: w0 * p0 + w1 * p1 + w2 * p2, left to right (interpolate_gpu.cu:95-96)
-#define EPNET_TI_ROW(F_)                                                                                      \
-    store_stream(dst, w[0][0] * v[0][0].F_ + w[0][1] * v[0][1].F_ + w[0][2] * v[0][2].F_,                     \
-                 w[1][0] * v[1][0].F_ + w[1][1] * v[1][1].F_ + w[1][2] * v[1][2].F_,                          \
-                 w[2][0] * v[2][0].F_ + w[2][1] * v[2][1].F_ + w[2][2] * v[2][2].F_,                          \
-                 w[3][0] * v[3][0].F_ + w[3][1] * v[3][1].F_ + w[3][2] * v[3][2].F_);                         \
+#define EPNET_TI_VAL(u_, F_) (w[u_][0] * v[u_][0].F_ + w[u_][1] * v[u_][1].F_ + w[u_][2] * v[u_][2].F_)
+#define EPNET_TI_ROW(F_)                                                                                          \
+    if constexpr (U == 4) store_stream(dst, EPNET_TI_VAL(0, F_), EPNET_TI_VAL(1, F_), EPNET_TI_VAL(2, F_), EPNET_TI_VAL(3, F_)); \
+    else __builtin_nontemporal_store(EPNET_TI_VAL(0, F_), dst);                                                    \
     dst += n;
             EPNET_TI_ROW(x)
             EPNET_TI_ROW(y)
             EPNET_TI_ROW(z)
             EPNET_TI_ROW(w)
 #undef EPNET_TI_ROW
+#undef EPNET_TI_VAL
             quad += m;
         }
     }
@@ -680,26 +681,42 @@ extern "C" int epnet_three_interpolate(int b, int c, int m, int n, const float *
     EPNET_REQUIRE(points && idx && weight && out);
     if (b > 65535 || div_up(c, kTiChan) > 65535) return EPNET_ELIMIT;
     constexpr int kLdsBudget = 64 * 1024;
-    if (c >= 8 && (n % 4) == 0 && n >= 2048 && (size_t)m * 4 <= kLdsBudget && ((uintptr_t)out % 16) == 0) {
+    const bool quad_ok = (c & 3) == 0 && (m & 3) == 0 && ((uintptr_t)points & 15) == 0;
+    if (c >= 8 && (n % 4) == 0 && n >= 1024 && (size_t)m * 4 <= kLdsBudget && ((uintptr_t)out % 16) == 0) {
         int rows = kLdsBudget / (m * 4);
         if (rows > c) rows = c;
         if (rows > 32) rows = 32;
         if ((c & 3) == 0 && rows >= 4) rows &= ~3;  // whole groups of four channels for the interleaved kernel
         const int chunks = div_up(c, rows);
         int tiles = div_up(1024, b * chunks);
-        const int max_tiles = n / 2048;
+        const int max_tiles = max(1, n / 2048);
         if (tiles > max_tiles) tiles = max_tiles;
         if (tiles < 1) tiles = 1;
         int tile = div_up(n, tiles);
         tile = (tile + 1023) / 1024 * 1024;
         tiles = div_up(n, tile);
         if (chunks <= 65535) {
-            if ((c & 3) == 0 && (m & 3) == 0 && (rows & 3) == 0 && ((uintptr_t)points & 15) == 0)
-                hipLaunchKernelGGL(three_interpolate_lds4_kernel, dim3(tiles, chunks, b), dim3(kTiThreads), (size_t)rows * m * 4,
+            if (quad_ok && (rows & 3) == 0)
+                hipLaunchKernelGGL(three_interpolate_lds4_kernel<4>, dim3(tiles, chunks, b), dim3(kTiThreads), (size_t)rows * m * 4,
                                    (hipStream_t)stream, c, m, n, rows, tile, points, idx, weight, out);
             else
                 hipLaunchKernelGGL(three_interpolate_lds_kernel, dim3(tiles, chunks, b), dim3(kTiThreads), (size_t)rows * m * 4,
                                    (hipStream_t)stream, c, m, n, rows, tile, points, idx, weight, out);
+            return check_launch("three_interpolate");
+        }
+    }
+    // the coarse levels of the FP pyramid (64 -> 256, 256 -> 1024 points, 512 - 1024 channels): a thread per unknown, more channel
+    // rows per workgroup (the known rows are short). The direct kernel below runs these shapes at 1.7 TB/s
+    if (quad_ok && c >= 8 && n >= 64 && n < 1024 && m >= 4 && (size_t)m * 16 <= kLdsBudget) {
+        int rows = kLdsBudget / (m * 4);
+        if (rows > c) rows = c;
+        if (rows > 64) rows = 64;
+        rows &= ~3;
+        const int chunks = div_up(c, rows);
+        const int tile = (n + kTiThreads - 1) / kTiThreads * kTiThreads;   // one tile: n < 1024 = 4 passes of the workgroup at most
+        if (rows >= 4 && chunks <= 65535) {
+            hipLaunchKernelGGL(three_interpolate_lds4_kernel<1>, dim3(1, chunks, b), dim3(kTiThreads), (size_t)rows * m * 4,
+                               (hipStream_t)stream, c, m, n, rows, tile, points, idx, weight, out);
             return check_launch("three_interpolate");
         }
     }

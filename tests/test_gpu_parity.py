@@ -697,7 +697,9 @@ def test_sa_module_follows_a_refilled_cloud_and_a_graph_replay():
 
 
 @pytest.mark.parametrize("b,c,m,n", [(2, 256, 64, 256), (2, 128, 1024, 4096), (1, 7, 50, 333), (2, 16, 9, 2), (2, 40, 4096, 16384),
-                                     (1, 4096, 4096, 16384)])   # enough workgroups for the run-partitioned gradient
+                                     (1, 4096, 4096, 16384),    # enough workgroups for the run-partitioned gradient
+                                     (3, 1024, 64, 256), (2, 512, 256, 1024),   # the coarse FP levels of the RPN (thread-per-unknown / one-tile LDS kernels)
+                                     (2, 24, 8, 100), (1, 200, 4092, 1023), (2, 12, 64, 64)])   # ragged n, long known rows, smallest n of that path
 def test_three_interpolate_and_grad(oracle, b, c, m, n):
     from epnet_amd import pointnet2_cuda as ext
     rng = np.random.default_rng(c + m)
