@@ -451,6 +451,12 @@ extern "C" int epnet_debug_runsum_stats(unsigned long long *host16) {
     (void)hipMemcpyToSymbol(HIP_SYMBOL(runsum::g_runsum_stats), zero, sizeof(zero));
     return 0;
 }
+extern "C" int epnet_debug_pack_stats(unsigned long long *host8) {
+    (void)hipMemcpyFromSymbol(host8, HIP_SYMBOL(runsum::g_pack_stats), sizeof(unsigned long long) * 8);
+    unsigned long long zero[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(runsum::g_pack_stats), zero, sizeof(zero));
+    return 0;
+}
 #endif
 
 #ifdef EPNET_NN_STATS

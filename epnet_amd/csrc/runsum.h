@@ -31,6 +31,7 @@ namespace runsum {
 
 #ifdef EPNET_RUNSUM_STATS  // diagnostic build only (profiles/micro/runsum_stats.py): phase cycle counters of the scatter kernel
 __device__ unsigned long long g_runsum_stats[16];   // [0..7]: wave 0 of every workgroup, [8..15]: its last wave
+__device__ unsigned long long g_pack_stats[8];      // pack_kernel, wave 0: count pass, scans, placing pass, padding, workgroups
 #define EPNET_RS_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
 #define EPNET_RS_ACC(slot, a, b) rs_acc[slot] += (unsigned long long)((b) - (a))
 #define EPNET_RS_BEGIN unsigned long long rs_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
@@ -106,7 +107,7 @@ template <bool W>
 __global__ __launch_bounds__(kThreads) void pack_kernel(int n, int p, int div, size_t idx_stride, const int *__restrict__ idx,
                                                         const float *__restrict__ weight, unsigned *__restrict__ ent,
                                                         float *__restrict__ wsorted) {
-    extern __shared__ int s_bins[];  // counts (nb), then run starts (nb + 1)
+    extern __shared__ int s_bins[];  // counts (nb), then run starts (nb + 1), then a dummy counter per thread
     __shared__ int s_part[kThreads / 64];
     __shared__ int s_below[kThreads / 64];
     const int q = threadIdx.x, lane = q & 63, wave = q >> 6;
@@ -123,16 +124,31 @@ __global__ __launch_bounds__(kThreads) void pack_kernel(int n, int p, int div, s
     int *s_cnt = s_bins, *s_start = s_bins + nb;
     for (int i = q; i < nb; i += kThreads) s_cnt[i] = 0;
     __syncthreads();
+    EPNET_RS_STAMP(p_a);
+    // (both passes over the entries: kUnroll targets are requested together and their LDS atomics issued back to back -- one at a
+    // time every iteration is a chain of an L2 load, a returning LDS atomic and a dependent LDS read. The unrolled body has no
+    // bounds checks at all -- the compiler sinks a load whose value is only used under `t < p` into that branch and waits for
+    // it on the spot -- and the last partial block goes one entry at a time)
+    constexpr int kUnroll = 8;
     int below = 0;
-    for (int t = q; t < p; t += kThreads) {
-        const int j = min(max(idx[t], 0), n - 1);
+    auto count = [&](int j) {
         if (j < j0) ++below;
         else if (j < j1) atomicAdd(&s_cnt[j - j0], 1);
+    };
+    int t0 = q;
+    for (; t0 + (kUnroll - 1) * kThreads < p; t0 += kThreads * kUnroll) {
+        int js[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) js[u] = min(max(idx[t0 + u * kThreads], 0), n - 1);
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) count(js[u]);
     }
+    for (int t = t0; t < p; t += kThreads) count(min(max(idx[t], 0), n - 1));
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) below += __shfl_xor(below, off, 64);
     if (lane == 0) s_below[wave] = below;
     __syncthreads();
+    EPNET_RS_STAMP(p_b);
     const int per = (nb + kThreads - 1) / kThreads;
     int sum = 0;
     for (int i = 0; i < per; ++i) {
@@ -159,16 +175,61 @@ __global__ __launch_bounds__(kThreads) void pack_kernel(int n, int p, int div, s
         s_start[nb] = total;
     }
     __syncthreads();
-    for (int t = q; t < p; t += kThreads) {
-        const int j = min(max(idx[t], 0), n - 1);
-        if (j < j0 || j >= j1) continue;
-        const int old = atomicSub(&s_cnt[j - j0], 1);  // the run is filled from its end: old = entries still to place
+    EPNET_RS_STAMP(p_c);
+    const unsigned div_magic = div == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)div + 1ull);   // (div == 1: see below)
+    auto place = [&](int j, int t, int old) {   // the run is filled from its end: old = entries still to place
         const int slot = s_start[j - j0] + old - 1;
         const unsigned end = (slot + 1 == s_start[j - j0 + 1]) ? 0x80000000u : 0u;
         const int at = slot_to_mem(slot, ept);
-        ent[at] = end | ((unsigned)j << 16) | (unsigned)(t / div);
-        if (W) wsorted[at] = weight[t];
+        ent[at] = end | ((unsigned)j << 16) | (div == 1 ? (unsigned)t : __umulhi((unsigned)t, div_magic));   // == t / div (t * div < 2^32)
+        if (W) wsorted[at] = weight[t];   // (only the workgroup that owns the target reads the weight)
+    };
+    // unrolled: every step of the kUnroll entries is issued for all of them before any result is used, with no branch in between
+    // (an entry of another workgroup's range goes through the motions on the thread's dummy counter): loads, returning atomics, run
+    // bounds and weights are one wait each instead of kUnroll chains of four waits
+    int *s_dummy = s_bins + 2 * nb + 1 + q;   // (a word per thread: one shared dummy would serialise the atomics of a wave)
+    t0 = q;
+    for (; t0 + (kUnroll - 1) * kThreads < p; t0 += kThreads * kUnroll) {
+        int js[kUnroll], olds[kUnroll], starts[kUnroll], nexts[kUnroll];
+        float ws[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            js[u] = min(max(idx[t0 + u * kThreads], 0), n - 1);
+            ws[u] = W ? weight[t0 + u * kThreads] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const bool mine = js[u] >= j0 && js[u] < j1;
+            js[u] = mine ? js[u] - j0 : -1;
+            olds[u] = atomicSub(mine ? &s_cnt[js[u]] : s_dummy, 1);
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            starts[u] = s_start[max(js[u], 0)];
+            nexts[u] = s_start[max(js[u], 0) + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            if (js[u] < 0) continue;
+            const int slot = starts[u] + olds[u] - 1;
+            const unsigned end = (slot + 1 == nexts[u]) ? 0x80000000u : 0u;
+            const int at = slot_to_mem(slot, ept);
+            const unsigned t = (unsigned)(t0 + u * kThreads);
+            ent[at] = end | ((unsigned)(js[u] + j0) << 16) | (div == 1 ? t : __umulhi(t, div_magic));
+            if (W) wsorted[at] = ws[u];
+        }
     }
+    for (int t = t0; t < p; t += kThreads) {
+        const int j = min(max(idx[t], 0), n - 1);
+        if (j >= j0 && j < j1) place(j, t, atomicSub(&s_cnt[j - j0], 1));
+    }
+    EPNET_RS_STAMP(p_d);
+#ifdef EPNET_RUNSUM_STATS
+    if (q == 0) {
+        atomicAdd(&g_pack_stats[0], p_b - p_a); atomicAdd(&g_pack_stats[1], p_c - p_b); atomicAdd(&g_pack_stats[2], p_d - p_c);
+        atomicAdd(&g_pack_stats[4], 1ull);
+    }
+#endif
     if (part == parts - 1)  // padding: entries of a dump target (key n) that read position 0 with weight 0, every one a run
         for (int s = p + q; s < P; s += kThreads) {  // of its own (ONE long run would be handed from thread to thread)
             const int at = slot_to_mem(s, ept);
@@ -424,7 +485,8 @@ inline int launch(int b, int c, int n, int div, int row_floats, const float *gra
     const int tile = tile_floats(n, div, row_floats);
     const size_t idx_stride = (size_t)row_floats * div;
     // parts: enough workgroups to spread the counting sort over the chip, each with at least a few hundred targets
-    int parts = b >= 128 ? 1 : b >= 32 ? 4 : b >= 8 ? 8 : 16;
+    int parts = b >= 128 ? 2 : b >= 32 ? 8 : 16;
+    if (const char *e = getenv("EPNET_RUNSUM_PARTS")) parts = atoi(e) > 0 ? atoi(e) : parts;  // (tuning)
     while (parts > 1 && n / parts < 256) parts >>= 1;
     const int nb = div_up(n, parts);
     const int vec_out = ((n & 3) == 0 && ((uintptr_t)grad_points & 15) == 0) ? 1 : 0;
@@ -434,7 +496,7 @@ inline int launch(int b, int c, int n, int div, int row_floats, const float *gra
         const int P = padded_entries(entries);
         unsigned *ent = (unsigned *)workspace;
         float *wsorted = W ? (float *)(ent + (size_t)b * P) : nullptr;
-        hipLaunchKernelGGL((pack_kernel<W>), dim3(parts, b), dim3(kThreads), (size_t)(2 * nb + 1) * sizeof(int), s, n, entries, div,
+        hipLaunchKernelGGL((pack_kernel<W>), dim3(parts, b), dim3(kThreads), (size_t)(2 * nb + 1 + kThreads) * sizeof(int), s, n, entries, div,
                            idx_stride, idx + (size_t)pos0 * div, W ? weight + (size_t)pos0 * div : nullptr, ent, wsorted);
         int rc = check_launch("inverse index");
         if (rc) return rc;

@@ -38,3 +38,9 @@ if has:
     for k, name in enumerate(["copy rows to LDS + barrier", "entry loop", "barrier after loop", "head / far links + barrier", "output rows"]):
         print("   %-28s first wave %8.1f   last wave %8.1f   ticks of s_memtime per row pass (x %d row passes)"
               % (name, out[k] / rows, out[8 + k] / rows, rows))
+    if hasattr(lib, "epnet_debug_pack_stats"):
+        pk = (ctypes.c_ulonglong * 8)()
+        lib.epnet_debug_pack_stats(pk)
+        wgs = pk[4] or 1
+        for k, name in enumerate(["count pass", "scans", "placing pass"]):
+            print("   pack: %-20s %8.1f ticks per workgroup (x %d)" % (name, pk[k] / wgs, wgs))
