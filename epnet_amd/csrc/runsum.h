@@ -366,7 +366,7 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(int c, int n, int row
         float4 oldv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (have_old) oldv = reinterpret_cast<const float4 *>(gp + (size_t)(c0 + q / n4) * n)[q - (q / n4) * n4];
         // Branch-free walk over the thread's entries: EVERY entry stores the running sum of its run -- the last entry of a run
-        // (and the thread's last entry, whose run the next thread may continue) to the output row slot of its target, an entry
+        // to the output row slot of its target, an entry
         // inside the run the thread's range began in to the hand-over slot, every other entry to the thread's private dump
         // word. (Neighbouring lanes hold neighbouring targets, a few words apart: with every running sum going to its target's
         // slot the stores of a wave met in a quarter of the banks, 4 to 8 lanes deep, and set the pace of the whole kernel; the
@@ -375,11 +375,15 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(int c, int n, int row
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = 0.f;
         bool first_open = open_start;
+        // where a running sum goes that is not a finished run's: the hand-over slot while inside the run the range began in, the
+        // thread's dump word afterwards (kept as one value: a select per entry instead of two)
+        const int dump_slot = (int)(s_dump - s_out) + q;
+        int priv = open_start ? (int)(s_first - s_out) + q : dump_slot;
         // the entry words of kAhead groups of four are in flight ahead of the sums (they come from L2 at best). The ring's slots
         // are static (the loop is unrolled by its length) and every load is UNCONDITIONAL (past the end it repeats the last
         // group): only then can the compiler count the loads in flight and wait for exactly the group it needs -- with a
         // conditional load it falls back to `s_waitcnt vmcnt(0)` at every use, i.e. no prefetch at all
-        auto sum_group = [&](const uint4 e4, const float4 w4, const bool last_group) __attribute__((always_inline)) {
+        auto sum_group = [&](const uint4 &e4, const float4 &w4) __attribute__((always_inline)) {
             const unsigned es[4] = {e4.x, e4.y, e4.z, e4.w};
             const float ws[4] = {w4.x, w4.y, w4.z, w4.w};
             float v[4][R];  // all reads of the group before any store (the stores go to the same LDS array: the compiler
@@ -393,31 +397,36 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(int c, int n, int row
                 const unsigned e = es[k];
                 const int key = (int)((e >> 16) & 0x7FFFu);
                 const bool end = (int)e < 0;
-                const bool real = !first_open && (end || (k == 3 && last_group));
-                // index relative to s_out, row 0
-                const int slot = real ? key : (first_open ? (int)(s_first - s_out) + q : (int)(s_dump - s_out) + q);
+                const bool real = !first_open && end;
+                const int slot = real ? key : priv;   // index relative to s_out, row 0
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     acc[r] += W ? v[k][r] * ws[k] : v[k][r];
                     s_out[(real ? r * n_pad : r * kThreads) + slot] = acc[r];
                     acc[r] = end ? 0.f : acc[r];
                 }
+                priv = end ? dump_slot : priv;   // (the hand-over slot only up to the end of the run the range began in)
                 first_open = first_open && !end;
             }
         };
+        const float4 ones = make_float4(1.f, 1.f, 1.f, 1.f);
         int g0 = 0;
         for (; g0 + kAhead <= nq; g0 += kAhead) {
 #pragma unroll
             for (int j = 0; j < kAhead; ++j) {
-                const uint4 e4 = ering[j];
-                const float4 w4 = W ? wring[j] : make_float4(1.f, 1.f, 1.f, 1.f);
-                load_group(j, min(g0 + j + kAhead, nq - 1));
-                sum_group(e4, w4, g0 + j + 1 == nq);
+                sum_group(ering[j], W ? wring[j] : ones);              // (summed out of the ring's registers, refilled
+                load_group(j, min(g0 + j + kAhead, nq - 1));           //  afterwards: no copies, no rotation)
             }
         }
 #pragma unroll
         for (int j = 0; j < kAhead - 1; ++j)   // the nq % kAhead groups left over (their words are in the ring's first slots)
-            if (g0 + j < nq) sum_group(ering[j], W ? wring[j] : make_float4(1.f, 1.f, 1.f, 1.f), g0 + j + 1 == nq);
+            if (g0 + j < nq) sum_group(ering[j], W ? wring[j] : ones);
+        // the run this thread's range ends inside of (and begins in) has no last entry here: its running sum goes to its target's
+        // slot now, where the hand-over step below completes it
+        if (head) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) s_out[r * n_pad + last_key] = acc[r];
+        }
         // the first groups' words again for the next pass (the same words every pass), ahead of the rows
 #pragma unroll
         for (int j = 0; j < kAhead; ++j) load_group(j, min(j, nq - 1));
