@@ -419,19 +419,23 @@ __global__ __launch_bounds__(kGThreads) void group_linear_grad_w_kernel(int c, i
     float acc[kGwRows][3];
 #pragma unroll
     for (int r = 0; r < kGwRows; ++r) acc[r][0] = acc[r][1] = acc[r][2] = 0.f;
+    // (a full chunk of rows reads them without a guard: a load under `r < nr` is waited for before the next one is issued --
+    // eight serial round trips per position; the last, partial chunk of a channel count that is no multiple of kGwRows reads
+    // its last row again instead and drops the products)
     for (int q = q_begin + threadIdx.x; q < q_end; q += kGThreads) {
         const int id = ix[q];
         const float *pt = pts + (size_t)id * 3;
         const float *ce = new_xyz + ((size_t)bs * npoints + q / nsample) * 3;
+        float gv[kGwRows];
+#pragma unroll
+        for (int r = 0; r < kGwRows; ++r) gv[r] = g[(size_t)min(r, nr - 1) * p + q];
         const float dx = pt[0] - ce[0], dy = pt[1] - ce[1], dz = pt[2] - ce[2];
 #pragma unroll
         for (int r = 0; r < kGwRows; ++r) {
-            if (r < nr) {
-                const float gv = g[(size_t)r * p + q];
-                acc[r][0] += gv * dx;
-                acc[r][1] += gv * dy;
-                acc[r][2] += gv * dz;
-            }
+            const float gr = r < nr ? gv[r] : 0.f;
+            acc[r][0] += gr * dx;
+            acc[r][1] += gr * dy;
+            acc[r][2] += gr * dz;
         }
     }
     const int lane = lane_id(), wave = threadIdx.x >> 6;

@@ -80,12 +80,16 @@ __global__ __launch_bounds__(kSampleThreads) void feature_gather_kernel(int c, i
     const int c0 = blockIdx.y * chunk, c1 = min(c, c0 + chunk);
     const float *plane = fmap + ((size_t)bs * c + c0) * h * w;
     float *dst = out + ((size_t)bs * c + c0) * n + q;
+    // the four taps of a channel are requested together: a tap outside the map reads the map's first pixel instead and its
+    // product is dropped (a load under `if (inside)` is waited for before the next one is issued: four serial round trips)
+    const long long a_nw = i_nw ? o_nw : 0, a_ne = i_ne ? o_nw + 1 : 0, a_sw = i_sw ? o_nw + w : 0, a_se = i_se ? o_nw + w + 1 : 0;
     for (int ci = c0; ci < c1; ++ci) {
+        const float p_nw = plane[a_nw], p_ne = plane[a_ne], p_sw = plane[a_sw], p_se = plane[a_se];
         float v = 0.f;
-        if (i_nw) v += plane[o_nw] * t.nw;
-        if (i_ne) v += plane[o_nw + 1] * t.ne;
-        if (i_sw) v += plane[o_nw + w] * t.sw;
-        if (i_se) v += plane[o_nw + w + 1] * t.se;
+        v += i_nw ? p_nw * t.nw : 0.f;
+        v += i_ne ? p_ne * t.ne : 0.f;
+        v += i_sw ? p_sw * t.sw : 0.f;
+        v += i_se ? p_se * t.se : 0.f;
         *dst = v;
         plane += (size_t)h * w;
         dst += n;
