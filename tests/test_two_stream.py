@@ -179,16 +179,30 @@ def test_full_size_two_stream_backbone_against_stock_sampler(hiplib):
 
     def rel_l2(a, b):
         return float((a - b).norm() / b.norm().clamp_min(floor))
-    assert rel_l2(gi_hip, gi_stock) < 5e-3, rel_l2(gi_hip, gi_stock)
+    # Which ReLUs flip differs from run to run (float atomics in both samplers' backward passes, MIOpen's own): the image gradient
+    # was seen at 1e-3 .. 9e-3 over repeated runs of the same build, so the training-mode bounds only say "no O(1) error"; the
+    # tight comparison of the gradients is the eval-mode one below
+    assert rel_l2(gi_hip, gi_stock) < 3e-2, rel_l2(gi_hip, gi_stock)
     worst = max(((rel_l2(gp_hip[k], gp_stock[k]), k) for k in gp_stock), key=lambda t: t[0])
-    assert worst[0] < 5e-2, worst            # (a scalar bias summing attention gradients over 8192 points: 1.3 % observed)
+    assert worst[0] < 1e-1, worst            # (a scalar bias summing attention gradients over 8192 points: 1.3 % observed)
     whole_hip = torch.cat([gp_hip[k].flatten() for k in gp_stock])
     whole_stock = torch.cat([gp_stock[k].flatten() for k in gp_stock])
-    assert rel_l2(whole_hip, whole_stock) < 5e-3, rel_l2(whole_hip, whole_stock)
-    with torch.no_grad():
-        outs = []
-        for model in (hip, stock):
-            model.load_state_dict(hip.state_dict())
-            model.eval()
-            outs.append(model(pts.clone(), image.clone(), xy.clone())[1])
-    torch.testing.assert_close(outs[0], outs[1], rtol=1e-4, atol=2e-5)
+    assert rel_l2(whole_hip, whole_stock) < 3e-2, rel_l2(whole_hip, whole_stock)
+    # eval mode (batch norm by its running statistics: no renormalisation by the batch, nothing amplified): outputs to 1e-4 / 2e-5,
+    # gradients of the image and of all parameters to 2e-3 of their norm
+    outs = []
+    for model in (hip, stock):
+        model.load_state_dict(hip.state_dict())
+        model.zero_grad(set_to_none=True)
+        model.eval()
+        img = image.clone().requires_grad_(True)
+        feats = model(pts.clone(), img, xy.clone())[1]
+        (feats * probe).sum().backward()
+        outs.append((feats.detach(), img.grad, {k: p.grad for k, p in model.named_parameters() if p.grad is not None}))
+    (e_hip, egi_hip, egp_hip), (e_stock, egi_stock, egp_stock) = outs
+    torch.testing.assert_close(e_hip, e_stock, rtol=1e-4, atol=2e-5)
+    floor = 1e-3 * max(float(g_.norm()) for g_ in egp_stock.values())
+    assert rel_l2(egi_hip, egi_stock) < 2e-3, rel_l2(egi_hip, egi_stock)
+    whole_hip = torch.cat([egp_hip[k].flatten() for k in egp_stock])
+    whole_stock = torch.cat([egp_stock[k].flatten() for k in egp_stock])
+    assert rel_l2(whole_hip, whole_stock) < 2e-3, rel_l2(whole_hip, whole_stock)
