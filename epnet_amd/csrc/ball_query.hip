@@ -120,6 +120,13 @@ __global__ __launch_bounds__(kBqThreads) void ball_query_kernel(int n, int m, fl
 
 // T threads, 2^BITS grid cells: <1024, 14> for big scenes; <256, 12> for n <= 4096, where 4096 cells are plenty and a
 // workgroup of 4 waves with 18 KB of LDS finds room on a CU that the wide kernels of the pipelined stack occupy
+#ifdef EPNET_IX_STATS  // diagnostic build only (profiles/micro/ix_stats.py): phase counters of the index build (wave 0)
+__device__ unsigned long long g_ix_stats[8];
+#define EPNET_IX_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define EPNET_IX_STAMP(var)
+#endif
+
 template <int kIxThreads, int BITS>
 __global__ __launch_bounds__(kIxThreads) void bq_index_kernel(int n, int np, const float *__restrict__ xyz,
                                                               float4 *__restrict__ sorted, float *__restrict__ boxes,
@@ -142,21 +149,26 @@ __global__ __launch_bounds__(kIxThreads) void bq_index_kernel(int n, int np, con
     const bool in_regs = n <= kIxThreads * kIxPerThread;  // block-uniform
     float px[kIxPerThread], py[kIxPerThread], pz[kIxPerThread];
     float lo[3], ext[3];
+    EPNET_IX_STAMP(t_0);
     if (in_regs) {
         float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+        // all of a thread's points are requested before the first one is used, and nothing below branches on `k < n`: with the
+        // box update under an `if` every iteration was a basic block of its own and its load was waited for before the next
+        // was issued -- 16 serial trips to HBM at the head of the sampling chain of every level
 #pragma unroll
         for (int i = 0; i < kIxPerThread; ++i) {
             const int k = q + i * kIxThreads;
-            const bool ok = k < n;
-            const int kk = ok ? k : 0;
+            const int kk = k < n ? k : 0;
             px[i] = xyz[kk * 3 + 0];
             py[i] = xyz[kk * 3 + 1];
             pz[i] = xyz[kk * 3 + 2];
-            if (ok) {
-                mn[0] = fminf(mn[0], px[i]); mx[0] = fmaxf(mx[0], px[i]);
-                mn[1] = fminf(mn[1], py[i]); mx[1] = fmaxf(mx[1], py[i]);
-                mn[2] = fminf(mn[2], pz[i]); mx[2] = fmaxf(mx[2], pz[i]);
-            }
+        }
+#pragma unroll
+        for (int i = 0; i < kIxPerThread; ++i) {
+            const bool ok = q + i * kIxThreads < n;
+            mn[0] = fminf(mn[0], ok ? px[i] : 3.4e38f); mx[0] = fmaxf(mx[0], ok ? px[i] : -3.4e38f);
+            mn[1] = fminf(mn[1], ok ? py[i] : 3.4e38f); mx[1] = fmaxf(mx[1], ok ? py[i] : -3.4e38f);
+            mn[2] = fminf(mn[2], ok ? pz[i] : 3.4e38f); mx[2] = fmaxf(mx[2], ok ? pz[i] : -3.4e38f);
         }
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -181,20 +193,25 @@ __global__ __launch_bounds__(kIxThreads) void bq_index_kernel(int n, int np, con
         block_bbox3(xyz, n, s_box, lo, ext);
     }
     const CellGrid g = make_cell_grid(lo, ext, BITS);
+    EPNET_IX_STAMP(t_1);
     for (int i = q; i < kCells + kCells / per + 64; i += kIxThreads) s_hist[i] = 0;
     __syncthreads();
-    int code[kIxPerThread];
+    EPNET_IX_STAMP(t_2);
+    // in_regs: the histogram pass keeps what its atomics return -- a point's rank inside its cell -- so the scatter below needs
+    // no second round of atomics on the same (hot: a cell next to the sensor holds hundreds of points) words: 46 % of the kernel
+    int code[kIxPerThread], rank[kIxPerThread];
     if (in_regs) {
 #pragma unroll
-        for (int i = 0; i < kIxPerThread; ++i) {
-            code[i] = hist_at((int)cell_code(g, px[i], py[i], pz[i]), per_shift);
-            if (q + i * kIxThreads < n) atomicAdd(&s_hist[code[i]], 1);
-        }
+        for (int i = 0; i < kIxPerThread; ++i) code[i] = hist_at((int)cell_code(g, px[i], py[i], pz[i]), per_shift);
+#pragma unroll
+        for (int i = 0; i < kIxPerThread; ++i)   // (a slot beyond n counts on one of the 64 spare words behind the histogram)
+            rank[i] = atomicAdd(&s_hist[q + i * kIxThreads < n ? code[i] : kCells + kCells / per + lane], 1);
     } else {
         for (int k = q; k < n; k += kIxThreads)
             atomicAdd(&s_hist[hist_at((int)cell_code(g, xyz[k * 3 + 0], xyz[k * 3 + 1], xyz[k * 3 + 2]), per_shift)], 1);
     }
     __syncthreads();
+    EPNET_IX_STAMP(t_3);
     int sum = 0;
     for (int i = 0; i < per; ++i) sum += s_hist[hist_at(q * per + i, per_shift)];
     const int incl = wave_inclusive_scan(sum);
@@ -209,32 +226,13 @@ __global__ __launch_bounds__(kIxThreads) void bq_index_kernel(int n, int np, con
         base += c;
     }
     __syncthreads();
-    if (in_regs) {
-#pragma unroll
-        for (int i = 0; i < kIxPerThread; ++i) {
-            const int k = q + i * kIxThreads;
-            if (k < n) {
-                const int pos = atomicAdd(&s_hist[code[i]], 1);
-                sorted[pos] = make_float4(px[i], py[i], pz[i], __int_as_float(k));
-            }
-        }
-    } else {
-        for (int k = q; k < n; k += kIxThreads) {
-            const float x = xyz[k * 3 + 0], y = xyz[k * 3 + 1], z = xyz[k * 3 + 2];
-            const int pos = atomicAdd(&s_hist[hist_at((int)cell_code(g, x, y, z), per_shift)], 1);
-            sorted[pos] = make_float4(x, y, z, __int_as_float(k));
-        }
-    }
-    for (int p = n + q; p < np; p += kIxThreads)  // padding: never inside a ball
-        sorted[p] = make_float4(3.0e38f, 3.0e38f, 3.0e38f, __int_as_float(-1));
-    __threadfence_block();
-    __syncthreads();  // the scattered points are read back by other waves of this workgroup below
-    for (int p = q; p < np; p += kIxThreads) {  // one wave handles one bucket at a time
-        const float4 v = sorted[p];
+    EPNET_IX_STAMP(t_4);
+    auto bucket_box = [&](int p, const float4 v) {  // one wave handles one bucket at a time (all 64 lanes active)
         const bool real = p < n;
-        const float mnx = wave_minf_all(real ? v.x : 3.4e38f), mxx = wave_maxf_all(real ? v.x : -3.4e38f);
-        const float mny = wave_minf_all(real ? v.y : 3.4e38f), mxy = wave_maxf_all(real ? v.y : -3.4e38f);
-        const float mnz = wave_minf_all(real ? v.z : 3.4e38f), mxz = wave_maxf_all(real ? v.z : -3.4e38f);
+        const float cx_ = canonical(v.x), cy_ = canonical(v.y), cz_ = canonical(v.z);   // (quiet NaNs drop out of the box, as with fminf)
+        float mnx = real ? cx_ : 3.4e38f, mxx = real ? cx_ : -3.4e38f, mny = real ? cy_ : 3.4e38f, mxy = real ? cy_ : -3.4e38f,
+              mnz = real ? cz_ : 3.4e38f, mxz = real ? cz_ : -3.4e38f;
+        wave_box(mnx, mxx, mny, mxy, mnz, mxz);
         if (lane == 0) {
             float *bx = boxes + (p >> 6) * 6;
             const bool any = mnx <= mxx;  // an all-padding bucket gets a box no ball can reach
@@ -242,7 +240,66 @@ __global__ __launch_bounds__(kIxThreads) void bq_index_kernel(int n, int np, con
             bx[2] = any ? mny : 3.0e38f; bx[3] = any ? mxy : 3.0e38f;
             bx[4] = any ? mnz : 3.0e38f; bx[5] = any ? mxz : 3.0e38f;
         }
+    };
+    const bool staged = in_regs && (np & 255) == 0;  // (three_nn's own index of a known set pads to 64 only: no whole-bucket quarters)
+    if (staged) {
+        // The sorted order goes through LDS, a quarter of the scene at a time: the points land in the staging buffer (scattered
+        // 16-byte LDS writes), leave for global memory as whole rows (the scattered 16-byte global stores this replaces were
+        // 46 % of the kernel: 4 M partial-line writes per 256 scenes) and give their bucket boxes on the way out (no read-back
+        // of what was just written: another 20 %).
+        float4 *s_stage = reinterpret_cast<float4 *>(s_hist + kCells + kCells / per + 64);
+        int pos[kIxPerThread];
+#pragma unroll
+        for (int i = 0; i < kIxPerThread; ++i) pos[i] = s_hist[code[i]] + rank[i];   // start of the cell + rank inside it
+        const int quarter = np >> 2;  // a multiple of 64 (np is a power of two >= 2048)
+        for (int h = 0; h < 4; ++h) {
+            const int base = h * quarter;
+            for (int p = q; p < quarter; p += kIxThreads)   // padding rows: never inside a ball
+                if (base + p >= n) s_stage[p] = make_float4(3.0e38f, 3.0e38f, 3.0e38f, __int_as_float(-1));
+#pragma unroll
+            for (int i = 0; i < kIxPerThread; ++i) {
+                const int k = q + i * kIxThreads;
+                if (k < n && (unsigned)(pos[i] - base) < (unsigned)quarter)
+                    s_stage[pos[i] - base] = make_float4(px[i], py[i], pz[i], __int_as_float(k));
+            }
+            __syncthreads();
+            for (int p = q; p < quarter; p += kIxThreads) {
+                const float4 v = s_stage[p];
+                sorted[base + p] = v;
+                bucket_box(base + p, v);
+            }
+            __syncthreads();
+        }
+    } else {
+        if (in_regs) {
+#pragma unroll
+            for (int i = 0; i < kIxPerThread; ++i) {
+                const int k = q + i * kIxThreads;
+                if (k < n) sorted[s_hist[code[i]] + rank[i]] = make_float4(px[i], py[i], pz[i], __int_as_float(k));
+            }
+        } else {
+            for (int k = q; k < n; k += kIxThreads) {
+                const float x = xyz[k * 3 + 0], y = xyz[k * 3 + 1], z = xyz[k * 3 + 2];
+                const int pos = atomicAdd(&s_hist[hist_at((int)cell_code(g, x, y, z), per_shift)], 1);
+                sorted[pos] = make_float4(x, y, z, __int_as_float(k));
+            }
+        }
+        for (int p = n + q; p < np; p += kIxThreads)  // padding: never inside a ball
+            sorted[p] = make_float4(3.0e38f, 3.0e38f, 3.0e38f, __int_as_float(-1));
+        __threadfence_block();
+        __syncthreads();  // the scattered points are read back by other waves of this workgroup below
+        for (int p = q; p < np; p += kIxThreads) bucket_box(p, sorted[p]);
     }
+#ifdef EPNET_IX_STATS
+    {
+        EPNET_IX_STAMP(t_6);
+        if (q == 0) {
+            atomicAdd(&g_ix_stats[0], t_1 - t_0); atomicAdd(&g_ix_stats[1], t_2 - t_1); atomicAdd(&g_ix_stats[2], t_3 - t_2);
+            atomicAdd(&g_ix_stats[3], t_4 - t_3); atomicAdd(&g_ix_stats[4], t_6 - t_4);
+            atomicAdd(&g_ix_stats[7], 1ull);
+        }
+    }
+#endif
     if (!qboxes) return;
     // second level: one box per 4 consecutive buckets (256 sorted points)
     qboxes += (size_t)blockIdx.x * (np / 256) * 6;
@@ -606,12 +663,15 @@ int epnet::spatial_index_launch(int b, int n, int np, const float *xyz, float4 *
                                 hipStream_t s) {
     if (n <= 4096) {
         constexpr int T = 256, cells = 1 << 12;
-        hipLaunchKernelGGL((bq_index_kernel<T, 12>), dim3(b), dim3(T), (size_t)(cells + cells / (cells / T) + 64) * sizeof(int), s, n,
-                           np, xyz, sorted, boxes, qboxes);
+        // (+ the staging buffer of a quarter of the sorted scene: 8 - 16 KB here, 64 KB below)
+        const size_t stage = (np & 255) == 0 ? (size_t)(np / 4) * sizeof(float4) : 0;
+        hipLaunchKernelGGL((bq_index_kernel<T, 12>), dim3(b), dim3(T), (size_t)(cells + cells / (cells / T) + 64) * sizeof(int) + stage, s,
+                           n, np, xyz, sorted, boxes, qboxes);
     } else {
         constexpr int T = 1024, cells = 1 << 14;
-        hipLaunchKernelGGL((bq_index_kernel<T, 14>), dim3(b), dim3(T), (size_t)(cells + cells / (cells / T) + 64) * sizeof(int), s, n,
-                           np, xyz, sorted, boxes, qboxes);
+        const size_t stage = (n <= T * 16 && (np & 255) == 0) ? (size_t)(np / 4) * sizeof(float4) : 0;   // (bigger scenes scatter straight to global memory)
+        hipLaunchKernelGGL((bq_index_kernel<T, 14>), dim3(b), dim3(T), (size_t)(cells + cells / (cells / T) + 64) * sizeof(int) + stage, s,
+                           n, np, xyz, sorted, boxes, qboxes);
     }
     return check_launch("spatial index");
 }
@@ -727,3 +787,12 @@ extern "C" int epnet_ball_query_ws(int b, int n, int m, float radius, int nsampl
     if (rc) return rc;
     return epnet_ball_query_indexed(b, n, m, radius, nsample, new_xyz, xyz, workspace, workspace_bytes, idx, stream);
 }
+
+#ifdef EPNET_IX_STATS
+extern "C" int epnet_debug_ix_stats(unsigned long long *host8) {
+    (void)hipMemcpyFromSymbol(host8, HIP_SYMBOL(epnet::g_ix_stats), sizeof(unsigned long long) * 8);
+    unsigned long long zero[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(epnet::g_ix_stats), zero, sizeof(zero));
+    return 0;
+}
+#endif

@@ -97,4 +97,45 @@ __device__ __forceinline__ void row16_boxes(float x, float y, float z, float &lx
 #undef EPNET_ROWBOX_STEP
 }
 
+// v_min_f32 / v_max_f32 as they are (through fminf / fmaxf every operand is canonicalised first: three instructions per step).
+// Like fminf / fmaxf they return the other operand for a quiet NaN; a signalling NaN would come out quieted instead, so
+// canonicalise inputs of unknown origin once (canonical()) before a chain of these.
+__device__ __forceinline__ float min_raw(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float max_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float canonical(float v) { return __builtin_canonicalizef(v); }
+
+// Box of the wave's 64 points, result in every lane: lo* enter as the lanes' values for the minima, hi* for the maxima (a lane
+// that holds no point passes +-3.4e38; NaNs must be quiet: canonical()). 24 DPP steps inside the rows of 16 (as row16_boxes),
+// then the two row / half swaps: 48 vector instructions for the six numbers (wave_minf_all / wave_maxf_all: ~130).
+__device__ __forceinline__ void wave_box(float &lx, float &hx, float &ly, float &hy, float &lz, float &hz) {
+#define EPNET_WAVEBOX_STEP(ctl)                                        \
+    "v_min_f32_dpp %0, %0, %0 " ctl " row_mask:0xf bank_mask:0xf\n"     \
+    "v_max_f32_dpp %1, %1, %1 " ctl " row_mask:0xf bank_mask:0xf\n"     \
+    "v_min_f32_dpp %2, %2, %2 " ctl " row_mask:0xf bank_mask:0xf\n"     \
+    "v_max_f32_dpp %3, %3, %3 " ctl " row_mask:0xf bank_mask:0xf\n"     \
+    "v_min_f32_dpp %4, %4, %4 " ctl " row_mask:0xf bank_mask:0xf\n"     \
+    "v_max_f32_dpp %5, %5, %5 " ctl " row_mask:0xf bank_mask:0xf\n"
+    asm volatile("s_nop 1\n" EPNET_WAVEBOX_STEP("quad_perm:[1,0,3,2]") EPNET_WAVEBOX_STEP("quad_perm:[2,3,0,1]")
+                 EPNET_WAVEBOX_STEP("row_ror:4") EPNET_WAVEBOX_STEP("row_ror:8") "s_nop 1"
+                 : "+v"(lx), "+v"(hx), "+v"(ly), "+v"(hy), "+v"(lz), "+v"(hz));
+#undef EPNET_WAVEBOX_STEP
+    auto across = [](float v, bool is_min) {
+        const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = is_min ? min_raw(__uint_as_float(a[0]), __uint_as_float(a[1])) : max_raw(__uint_as_float(a[0]), __uint_as_float(a[1]));
+        const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        return is_min ? min_raw(__uint_as_float(b[0]), __uint_as_float(b[1])) : max_raw(__uint_as_float(b[0]), __uint_as_float(b[1]));
+    };
+    lx = across(lx, true);  hx = across(hx, false);
+    ly = across(ly, true);  hy = across(hy, false);
+    lz = across(lz, true);  hz = across(hz, false);
+}
+
 }  // namespace epnet
