@@ -89,9 +89,12 @@ class SAStack:
         # their index tensors to the next step's grouping, double-buffered) instead of in front of their grouping in stage G:
         #  * with the FP ops in the step stage G carries 2.2 ms of interpolation on top of the groupings: all of them
         #    (256-scene step with FP ops: 7.17 (everything in G) -> 6.60 (three_nn in S) -> 6.2 ms);
-        #  * without them, from ~192 scenes per step stage G (bandwidth-bound, grows with the batch) is the longer stage beside the
-        #    latency-bound sampling chain: the level-2 queries go to stage S (256 scenes: 3.45 - 3.55 -> 3.18 - 3.26 ms, 512 scenes
-        #    7.04 -> 6.54; all levels: 3.52, level 1 alone: 3.49; at 128 scenes stage S is the longer one: 2.62 -> 2.69, so not there).
+        #  * without them, from ~240 scenes per step stage G (bandwidth-bound, grows with the batch) is the longer stage beside the
+        #    latency-bound sampling chain: the queries of levels 2-4 go to stage S (256 scenes: 3.45 - 3.55 ms with every query in
+        #    stage G -> 3.18 - 3.26 with level 2's in S -> 3.11 - 3.13 with levels 2-4, once the scene index build had become
+        #    0.05 ms shorter; all levels: 3.52, level 1 alone: 3.49; at 128 scenes stage S is the longer one: 2.62 -> 2.69, so
+        #    not there, and
+        #    at 192 scenes 2.77 -> 2.88).
         # EPNET_SA_QUERIES_IN_S = 0: none, 1 (default): as above, 2: all levels; EPNET_SA_S_QUERY_LEVELS = "1,3": these (0-based)
         env_q = int(os.environ.get("EPNET_SA_QUERIES_IN_S", "1"))
         env_lv = os.environ.get("EPNET_SA_S_QUERY_LEVELS")
@@ -106,8 +109,8 @@ class SAStack:
             chosen = frozenset(int(v) for v in env_lv.split(",") if v.strip())
         elif env_q == 2 or (env_q == 1 and with_fp):
             chosen = every
-        elif env_q == 1 and batch * n >= 192 * 16384:
-            chosen = frozenset({1})
+        elif env_q == 1 and batch * n >= 240 * 16384:
+            chosen = every - {0}
         else:
             chosen = frozenset()
         self.s_query_levels = chosen & every
