@@ -487,7 +487,6 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
             unsigned cand = fold_parts<PPT>(__ballot(bm == wbest));
             racc = 0xFFFFFFFFu;
             hbuckets = 0ull;
-            int held = 0;  // points of this lane at the wave's maximum
             do {
                 const int j = (int)__builtin_ctz(cand);
                 cand &= cand - 1u;
@@ -497,7 +496,6 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
                 __builtin_amdgcn_sched_barrier(0);  // one GPR-index window for the four slot registers
                 const unsigned r = tj == wbest ? ((rw >> ((j & 1) << 4)) & 0xFFFFu) : 0xFFFFFFFFu;
                 if (r != 0xFFFFFFFFu) hbuckets |= 1ull << ((lane & ~(PPT - 1)) | j);  // summary lane of (slot j, my part)
-                held += r != 0xFFFFFFFFu ? 1 : 0;
                 const bool take = r < racc;  // a lane holding the maximum in two of its slots keeps the smaller rank
                 racc = take ? r : racc;
                 xa = take ? xj : xa;
@@ -505,8 +503,9 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
                 za = take ? zj : za;
             } while (cand);
             if (kTies) {
-                const unsigned long long holders = __ballot(held > 0);
-                wave_multi = (holders & (holders - 1ull)) != 0ull || __ballot(held > 1) != 0ull;
+                // (hbuckets has one bit per slot in which the lane holds the maximum)
+                const unsigned long long holders = __ballot(hbuckets != 0ull);
+                wave_multi = (holders & (holders - 1ull)) != 0ull || __ballot((hbuckets & (hbuckets - 1ull)) != 0ull) != 0ull;
             }
             if (wbest == kNeg1) {  // a wave of padding only
                 racc = 0xFFFFFFFFu;
