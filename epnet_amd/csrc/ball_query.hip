@@ -136,6 +136,9 @@ __global__ __launch_bounds__(kIxThreads) void bq_index_kernel(int n, int np, con
     __shared__ float s_box[6][16];
     __shared__ int s_part[16];
     const int q = threadIdx.x, lane = q & 63, wave = q >> 6;
+    // one workgroup per scene on the sampling chain of a level: beside the wide kernels of the pipelined stack (32 waves of a ball
+    // query per CU) its waves would get a ninth of the issue slots -- a 23 us build took 204 us there
+    __builtin_amdgcn_s_setprio(3);
     xyz += (size_t)blockIdx.x * n * 3;
     sorted += (size_t)blockIdx.x * np;
     boxes += (size_t)blockIdx.x * (np / 64) * 6;

@@ -1111,6 +1111,32 @@ __global__ __launch_bounds__(256) void gather_centres_kernel(int n, int m, const
     out[(size_t)bs * m * 3 + e] = xyz[((size_t)bs * n + idx[(size_t)bs * m + i]) * 3 + a];
 }
 
+// four centres per thread (one 16-byte load of indices, three 16-byte stores): a twelfth of the waves of the kernel above. The
+// gather sits on the sampling chain behind every level's FPS, and beside the wide kernels of the pipelined stack what a small
+// kernel waits for is wave slots (77 - 118 us for a copy that takes 8 alone)
+__global__ __launch_bounds__(256) void gather_centres4_kernel(int n, int m, const float *__restrict__ xyz,
+                                                              const int *__restrict__ idx, float *__restrict__ out) {
+    const int bs = blockIdx.y;
+    const int i4 = blockIdx.x * 256 + threadIdx.x;  // group of four centres
+    if (i4 * 4 >= m) return;
+    const int4 ids = reinterpret_cast<const int4 *>(idx + (size_t)bs * m)[i4];
+    const float *src = xyz + (size_t)bs * n * 3;
+    const float *p0 = src + (size_t)ids.x * 3, *p1 = src + (size_t)ids.y * 3, *p2 = src + (size_t)ids.z * 3, *p3 = src + (size_t)ids.w * 3;
+    const float a0 = p0[0], a1 = p0[1], a2 = p0[2], b0 = p1[0], b1 = p1[1], b2 = p1[2];
+    const float c0 = p2[0], c1 = p2[1], c2 = p2[2], d0 = p3[0], d1 = p3[1], d2 = p3[2];
+    float4 *dst = reinterpret_cast<float4 *>(out + ((size_t)bs * m + (size_t)i4 * 4) * 3);
+    dst[0] = make_float4(a0, a1, a2, b0);
+    dst[1] = make_float4(b1, b2, c0, c1);
+    dst[2] = make_float4(c2, d0, d1, d2);
+}
+
+static void launch_gather_centres(int b, int n, int m, const float *xyz, const int *idx, float *new_xyz, hipStream_t s) {
+    if ((m & 3) == 0 && (((uintptr_t)idx | (uintptr_t)new_xyz) & 15) == 0)
+        hipLaunchKernelGGL(gather_centres4_kernel, dim3(div_up(m / 4, 256), b), dim3(256), 0, s, n, m, xyz, idx, new_xyz);
+    else
+        hipLaunchKernelGGL(gather_centres_kernel, dim3(div_up(m * 3, 256), b), dim3(256), 0, s, n, m, xyz, idx, new_xyz);
+}
+
 // shared by the two entry points below; new_xyz may be NULL
 static int fps_over_index(int b, int n, int m, const float *xyz, const void *index, size_t index_bytes, float *temp, int *idx,
                           float *new_xyz, hipStream_t s, const int *skip = nullptr, int *prefix_out = nullptr,
@@ -1172,7 +1198,7 @@ static int fps_over_index(int b, int n, int m, const float *xyz, const void *ind
     if (rc || !new_xyz || centres_done) return rc;
     if (m == 0) return EPNET_OK;
     EPNET_REQUIRE(xyz && b <= 65535);
-    hipLaunchKernelGGL(gather_centres_kernel, dim3(div_up(m * 3, 256), b), dim3(256), 0, s, n, m, xyz, idx, new_xyz);
+    launch_gather_centres(b, n, m, xyz, idx, new_xyz, s);
     return check_launch("sample_centres gather");
 }
 
