@@ -110,13 +110,30 @@ __device__ __forceinline__ void find_slot(const int (&t)[PPT], const float (&x)[
     }
 }
 
+// What fps_prefix_kernel does for a scene, as the first thing of a sampling kernel (one workgroup per scene) that can do it
+// itself -- one dispatch less on the sampling chain of every level, where a dispatch beside the wide kernels of the pipelined
+// stack waits for wave slots (a 6 us prefix kernel was seen to take 77 us there). init < 0: a separate launch has done it.
+// Returns whether the scene's first m points are its samples already.
+__device__ __forceinline__ bool fps_prologue(int m, const int *__restrict__ skip, int *__restrict__ idx_scene,
+                                             int *__restrict__ prefix_out, int init) {
+    const int have = skip ? skip[blockIdx.x] : 0;
+    if (init >= 0) {
+        if (threadIdx.x == 0 && prefix_out) prefix_out[blockIdx.x] = have >= m ? have : init;
+        // (a scene whose rounds do run rewrites its indices itself; the known prefix is the same there)
+        for (int i = threadIdx.x; i < min(have, m); i += blockDim.x) idx_scene[i] = i;
+    }
+    return have >= m;
+}
+
 // Register-resident kernel: W waves per scene, PPT point slots per thread. 64*W <= bs = 2^lg_bs,
 // R = bs / (64*W), J = ceil(n / bs), R*J <= PPT.
 template <int W, int PPT>
 __global__ __launch_bounds__(64 * W) void fps_wave_kernel(int n, int m, int lg_bs, const float *__restrict__ xyz,
                                                           float *__restrict__ temp, int *__restrict__ idxs,
-                                                          const int *__restrict__ skip) {
-    if (skip && skip[blockIdx.x] >= m) return;  // this scene's first m points are the samples already (fps_prefix_kernel)
+                                                          const int *__restrict__ skip, int *__restrict__ prefix_out = nullptr,
+                                                          int prologue_init = -1) {
+    // this scene's first m points are the samples already?
+    if (fps_prologue(m, skip, idxs + (size_t)blockIdx.x * m, prefix_out, prologue_init)) return;
     __shared__ int s_val[2][16];     // per-wave maximum (bit pattern)
     __shared__ float4 s_rec[2][16];  // per-wave candidate: x, y, z, (q << 8 | slot) as int bits
     __shared__ int s_idx[kIdxBuf];
@@ -645,7 +662,7 @@ __global__ __launch_bounds__(64 * kW) void fps_indexed_kernel(int n, int m, cons
                                                               float *__restrict__ temp, int *__restrict__ idxs,
                                                               float *__restrict__ ctr, const int *__restrict__ prefix_in,
                                                               int *__restrict__ prefix_out, const float *__restrict__ xyz,
-                                                              int prefix_cap) {
+                                                              int prefix_cap, int prologue_init) {
     typedef float vecf __attribute__((ext_vector_type(PPT)));
     typedef int veci __attribute__((ext_vector_type(PPT)));
     constexpr int NP = 64 * kW * PPT;
@@ -653,7 +670,8 @@ __global__ __launch_bounds__(64 * kW) void fps_indexed_kernel(int n, int m, cons
     const int q = threadIdx.x;
     const int lane = q & 63, wave = q >> 6;
     const int known = prefix_in ? prefix_in[blockIdx.x] : 0;
-    if (known >= m) return;  // the first m points ARE the samples (fps_prefix_kernel wrote them)
+    // the first m points ARE the samples?
+    if (fps_prologue(m, prefix_in, idxs + (size_t)blockIdx.x * m, prefix_out, prologue_init)) return;
     sorted += (size_t)blockIdx.x * NP;
     if (temp) temp += (size_t)blockIdx.x * n;
     idxs += (size_t)blockIdx.x * m;
@@ -986,8 +1004,12 @@ using namespace epnet;
 // skip: per scene, "the first skip[b] points of xyz are an unambiguous furthest-point sequence" (scenes with skip[b] >= m are
 // left alone: fps_prefix_kernel has written their samples); prefix_out: per scene, receives the number of leading rounds of
 // THIS sampling whose maximum was unique (initialised by fps_prefix_kernel) where the kernel can tell. Both may be NULL.
+__global__ void fps_prefix_kernel(int m, const int *__restrict__ skip, int *__restrict__ idx, int *__restrict__ prefix_out, int init);
+
+// prologue_init >= 0: skip / prefix_out still want their fps_prefix_kernel treatment with that initial value -- folded into the
+// register-resident kernel, launched separately in front of the others
 static int fps_plain(int b, int n, int m, const float *xyz, float *temp, int *idx, const int *skip, int *prefix_out,
-                     epnet_stream_t stream, int prefix_cap = 0x7fffffff) {
+                     epnet_stream_t stream, int prefix_cap = 0x7fffffff, int prologue_init = -1) {
     EPNET_REQUIRE(b >= 0 && n >= 1 && m >= 0);
     if (b == 0 || m == 0) return EPNET_OK;  // the reference kernel returns at once for m <= 0
     EPNET_REQUIRE(xyz && idx);
@@ -1001,7 +1023,13 @@ static int fps_plain(int b, int n, int m, const float *xyz, float *temp, int *id
     // (the tuning variables are read on every call, so that the one-process GPU test run reaches every variant)
     const bool prune_enabled = !(getenv("EPNET_FPS_PRUNE") && atoi(getenv("EPNET_FPS_PRUNE")) == 0);
     const int prune_min = getenv("EPNET_FPS_PRUNE_MIN") ? atoi(getenv("EPNET_FPS_PRUNE_MIN")) : 1024;
+    auto prefix_first = [&]() -> int {   // the kernels below do not do the prologue themselves
+        if (prologue_init < 0) return EPNET_OK;
+        hipLaunchKernelGGL(fps_prefix_kernel, dim3(b), dim3(256), 0, s, m, skip, idx, prefix_out, prologue_init);
+        return check_launch("sampling prefix");
+    };
     if (prune_enabled && n > 1024 && n > prune_min && n <= 16384 && m > 1) {
+        if (int rc = prefix_first()) return rc;
         // 64-point slots: 4 waves x {8,16,32} slots, 8 waves above 8192 points (EPNET_FPS_PWAVES overrides)
         int waves = n > 8192 ? 8 : 4;
         if (const char *e = getenv("EPNET_FPS_PWAVES")) {
@@ -1047,7 +1075,7 @@ static int fps_plain(int b, int n, int m, const float *xyz, float *temp, int *id
         }
         const int ppt = (bs_ref / (64 * waves)) * J;
 #define EPNET_FPS_LAUNCH(W_, P_) \
-    hipLaunchKernelGGL((fps_wave_kernel<W_, P_>), grid, dim3(64 * W_), 0, s, n, m, lg, xyz, temp, idx, skip)
+    hipLaunchKernelGGL((fps_wave_kernel<W_, P_>), grid, dim3(64 * W_), 0, s, n, m, lg, xyz, temp, idx, skip, prefix_out, prologue_init)
 #define EPNET_FPS_PPT(W_)                      \
     do {                                       \
         if (ppt <= 1) EPNET_FPS_LAUNCH(W_, 1); \
@@ -1070,6 +1098,7 @@ static int fps_plain(int b, int n, int m, const float *xyz, float *temp, int *id
     // generic path: needs the running distances in memory
     float *tbuf = temp;
     if (!tbuf) return EPNET_EINVAL;  // temp may only be NULL on the register-resident path
+    if (int rc = prefix_first()) return rc;
     const int bs = bs_ref < 64 ? 64 : bs_ref;
     hipLaunchKernelGGL(fps_stream_kernel, grid, dim3(bs), 0, s, n, m, lg, xyz, tbuf, idx, skip);
     return check_launch("furthest_point_sampling");
@@ -1145,17 +1174,19 @@ static int fps_over_index(int b, int n, int m, const float *xyz, const void *ind
     bool centres_done = false;
     int rc;
     const bool plain = need == 0 || !index || n <= 1024 || m <= 1 || (n > 16384 && !temp);
+    int fold_init = -1;   // >= 0: the known prefixes / the tie-free counts still need their initial treatment (fps_prologue)
     if (skip || prefix_out) {
         EPNET_REQUIRE(idx && b <= 65535);
         if (prefix_cap < 1) prefix_cap = 0x7fffffff;
-        hipLaunchKernelGGL(fps_prefix_kernel, dim3(b), dim3(256), 0, s, m, skip, idx, prefix_out,
-                           fps_detects_ties(n, m, !plain) ? m : 0);
-        rc = check_launch("sampling prefix");
-        if (rc) return rc;
+        fold_init = fps_detects_ties(n, m, !plain) ? m : 0;
+    }
+    if (fold_init >= 0 && m == 0) {   // (no kernel below runs for m == 0)
+        hipLaunchKernelGGL(fps_prefix_kernel, dim3(b), dim3(256), 0, s, m, skip, idx, prefix_out, fold_init);
+        return check_launch("sampling prefix");
     }
     // n <= 1024: the reference block size (hence the tie-break rank) depends on n; the one-wave kernel handles it
     if (plain) {
-        rc = fps_plain(b, n, m, xyz, temp, idx, skip, prefix_out, (epnet_stream_t)s, prefix_cap);
+        rc = fps_plain(b, n, m, xyz, temp, idx, skip, prefix_out, (epnet_stream_t)s, prefix_cap, fold_init);
     } else {
         EPNET_REQUIRE(idx);
         if (index_bytes < need) return EPNET_ENOMEM;
@@ -1163,6 +1194,11 @@ static int fps_over_index(int b, int n, int m, const float *xyz, const void *ind
         dim3 grid(b);
         if (n > 16384) {  // beyond the register file: bucket summaries in registers, points re-read from the index
             EPNET_REQUIRE(xyz);
+            if (fold_init >= 0) {
+                hipLaunchKernelGGL(fps_prefix_kernel, dim3(b), dim3(256), 0, s, m, skip, idx, prefix_out, fold_init);
+                rc = check_launch("sampling prefix");
+                if (rc) return rc;
+            }
             const int np = scene_index_np(n);
             hipLaunchKernelGGL(pruned::fps_bigscene_kernel, grid, dim3(pruned::kBigThreads), 0, s, n, np, m, xyz, sorted,
                                (const float *)(sorted + (size_t)b * np), temp, scene_index_sampling_scratch(b, n, index), idx, skip);
@@ -1176,10 +1212,10 @@ static int fps_over_index(int b, int n, int m, const float *xyz, const void *ind
     do {                                                                                                                   \
         if (new_xyz && ctr_in_kernel)                                                                                      \
             hipLaunchKernelGGL((pruned::fps_indexed_kernel<W_, P_, true>), grid, dim3(64 * W_), 0, s, n, m, sorted, temp, \
-                               idx, new_xyz, skip, prefix_out, xyz, prefix_cap);                                           \
+                               idx, new_xyz, skip, prefix_out, xyz, prefix_cap, fold_init);                                \
         else                                                                                                               \
             hipLaunchKernelGGL((pruned::fps_indexed_kernel<W_, P_, false>), grid, dim3(64 * W_), 0, s, n, m, sorted, temp, \
-                               idx, (float *)nullptr, skip, prefix_out, xyz, prefix_cap);                                  \
+                               idx, (float *)nullptr, skip, prefix_out, xyz, prefix_cap, fold_init);                       \
     } while (0)
             switch (scene_index_np(n)) {
                 case 2048: EPNET_FPS_INDEXED(4, 8); break;
