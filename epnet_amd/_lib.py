@@ -52,6 +52,7 @@ SIGNATURES = {
     "epnet_pool_max_grad": (_i, [ctypes.c_longlong, _i, _vp, _vp, _vp, _vp]),
     "epnet_scene_index_bytes": (_sz, [_i, _i]),
     "epnet_scene_index_build": (_i, [_i, _i, _vp, _vp, _sz, _vp]),
+    "epnet_scene_index_build_gathered": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "epnet_furthest_point_sampling_indexed": (_i, [_i, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
     "epnet_sample_centres": (_i, [_i, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "epnet_sample_centres_chain": (_i, [_i, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _i, _vp]),

@@ -130,7 +130,9 @@ __device__ unsigned long long g_ix_stats[8];
 template <int kIxThreads, int BITS>
 __global__ __launch_bounds__(kIxThreads) void bq_index_kernel(int n, int np, const float *__restrict__ xyz,
                                                               float4 *__restrict__ sorted, float *__restrict__ boxes,
-                                                              float *__restrict__ qboxes) {
+                                                              float *__restrict__ qboxes, int n_src = 0,
+                                                              const int *__restrict__ src_idx = nullptr,
+                                                              float *__restrict__ gathered = nullptr) {
     constexpr int kCells = 1 << BITS;
     extern __shared__ int s_hist[];  // cell histogram / running offsets (spatial.h)
     __shared__ float s_box[6][16];
@@ -139,7 +141,14 @@ __global__ __launch_bounds__(kIxThreads) void bq_index_kernel(int n, int np, con
     // one workgroup per scene on the sampling chain of a level: beside the wide kernels of the pipelined stack (32 waves of a ball
     // query per CU) its waves would get a ninth of the issue slots -- a 23 us build took 204 us there
     __builtin_amdgcn_s_setprio(3);
-    xyz += (size_t)blockIdx.x * n * 3;
+    // src_idx (n <= kIxThreads * 16 only): the scene's points are rows src_idx[0 .. n) of a cloud of n_src points -- the centres a
+    // sampling has just picked -- and are written out in that order as well (gathered): the centre gather of an SA level and the
+    // index build of the next one in one dispatch
+    xyz += (size_t)blockIdx.x * (src_idx ? n_src : n) * 3;
+    if (src_idx) {
+        src_idx += (size_t)blockIdx.x * n;
+        gathered += (size_t)blockIdx.x * n * 3;
+    }
     sorted += (size_t)blockIdx.x * np;
     boxes += (size_t)blockIdx.x * (np / 64) * 6;
     // counting sort by cell, scattering the points (with their original index) straight to global memory.
@@ -158,13 +167,29 @@ __global__ __launch_bounds__(kIxThreads) void bq_index_kernel(int n, int np, con
         // all of a thread's points are requested before the first one is used, and nothing below branches on `k < n`: with the
         // box update under an `if` every iteration was a basic block of its own and its load was waited for before the next
         // was issued -- 16 serial trips to HBM at the head of the sampling chain of every level
+        int row[kIxPerThread];
 #pragma unroll
         for (int i = 0; i < kIxPerThread; ++i) {
             const int k = q + i * kIxThreads;
             const int kk = k < n ? k : 0;
-            px[i] = xyz[kk * 3 + 0];
-            py[i] = xyz[kk * 3 + 1];
-            pz[i] = xyz[kk * 3 + 2];
+            row[i] = src_idx ? src_idx[kk] : kk;
+        }
+#pragma unroll
+        for (int i = 0; i < kIxPerThread; ++i) {
+            px[i] = xyz[row[i] * 3 + 0];
+            py[i] = xyz[row[i] * 3 + 1];
+            pz[i] = xyz[row[i] * 3 + 2];
+        }
+        if (src_idx) {
+#pragma unroll
+            for (int i = 0; i < kIxPerThread; ++i) {
+                const int k = q + i * kIxThreads;
+                if (k < n) {
+                    gathered[k * 3 + 0] = px[i];
+                    gathered[k * 3 + 1] = py[i];
+                    gathered[k * 3 + 2] = pz[i];
+                }
+            }
         }
 #pragma unroll
         for (int i = 0; i < kIxPerThread; ++i) {
@@ -663,18 +688,18 @@ extern "C" int epnet_ball_query(int b, int n, int m, float radius, int nsample, 
 // shared with three_nn (interpolate.hip): cell-sorted float4 copy (x, y, z, original index) of n points padded
 // to np (a multiple of 64) per scene, plus one box (6 floats) per 64 sorted points
 int epnet::spatial_index_launch(int b, int n, int np, const float *xyz, float4 *sorted, float *boxes, float *qboxes,
-                                hipStream_t s) {
+                                hipStream_t s, int n_src, const int *src_idx, float *gathered) {
     if (n <= 4096) {
         constexpr int T = 256, cells = 1 << 12;
         // (+ the staging buffer of a quarter of the sorted scene: 8 - 16 KB here, 64 KB below)
         const size_t stage = (np & 255) == 0 ? (size_t)(np / 4) * sizeof(float4) : 0;
         hipLaunchKernelGGL((bq_index_kernel<T, 12>), dim3(b), dim3(T), (size_t)(cells + cells / (cells / T) + 64) * sizeof(int) + stage, s,
-                           n, np, xyz, sorted, boxes, qboxes);
+                           n, np, xyz, sorted, boxes, qboxes, n_src, src_idx, gathered);
     } else {
         constexpr int T = 1024, cells = 1 << 14;
         const size_t stage = (n <= T * 16 && (np & 255) == 0) ? (size_t)(np / 4) * sizeof(float4) : 0;   // (bigger scenes scatter straight to global memory)
         hipLaunchKernelGGL((bq_index_kernel<T, 14>), dim3(b), dim3(T), (size_t)(cells + cells / (cells / T) + 64) * sizeof(int) + stage, s,
-                           n, np, xyz, sorted, boxes, qboxes);
+                           n, np, xyz, sorted, boxes, qboxes, n_src, src_idx, gathered);
     }
     return check_launch("spatial index");
 }
@@ -729,6 +754,23 @@ extern "C" int epnet_scene_index_build(int b, int n, const float *xyz, void *ind
     float4 *sorted = (float4 *)index;
     float *boxes = (float *)(sorted + (size_t)b * np);
     return spatial_index_launch(b, n, np, xyz, sorted, boxes, boxes + (size_t)b * (np / 64) * 6, (hipStream_t)stream);
+}
+
+// the scene index of the n points xyz_src[idx[0 .. n)] of every scene (rows of a cloud of n_src points: the centres a sampling has
+// just picked), which are written to `gathered` (b, n, 3) in that order as well: gather_points + epnet_scene_index_build of an SA
+// level's centres in one dispatch. 1024 <= n <= 16384.
+extern "C" int epnet_scene_index_build_gathered(int b, int n_src, int n, const float *xyz_src, const int *idx, float *gathered,
+                                                void *index, size_t index_bytes, epnet_stream_t stream) {
+    const size_t need = scene_index_bytes(b, n);
+    EPNET_REQUIRE(need != 0 && n <= 16384 && n_src >= 1 && xyz_src && idx && gathered && index);
+    if (index_bytes < need) return EPNET_ENOMEM;
+    if (((uintptr_t)index & 15) != 0) return EPNET_EINVAL;
+    EPNET_REQUIRE(b <= 65535);
+    const int np = scene_index_np(n);
+    float4 *sorted = (float4 *)index;
+    float *boxes = (float *)(sorted + (size_t)b * np);
+    return spatial_index_launch(b, n, np, xyz_src, sorted, boxes, boxes + (size_t)b * (np / 64) * 6, (hipStream_t)stream, n_src, idx,
+                                gathered);
 }
 
 extern "C" int epnet_ball_query_indexed(int b, int n, int m, float radius, int nsample, const float *new_xyz,

@@ -1269,7 +1269,7 @@ extern "C" int epnet_sample_centres_chain(int b, int n, int m, const float *xyz,
                                           int prefix_cap, epnet_stream_t stream) {
     EPNET_REQUIRE(b >= 0 && n >= 1 && m >= 0);
     if (b == 0 || m == 0) return EPNET_OK;
-    EPNET_REQUIRE(xyz && idx && new_xyz);
+    EPNET_REQUIRE(xyz && idx);   // new_xyz may be NULL: the indices alone (the centres come from epnet_scene_index_build_gathered)
     if (m > n) prefix_in = nullptr;  // more samples than points: the sequence repeats points, nothing is known
     return fps_over_index(b, n, m, xyz, index, index_bytes, temp, idx, new_xyz, (hipStream_t)stream, prefix_in, prefix_out,
                           prefix_cap);

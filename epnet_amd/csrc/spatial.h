@@ -215,8 +215,8 @@ inline float *scene_index_sampling_scratch(int b, int n, const void *index) {
 }
 
 // defined in ball_query.hip
-// qboxes (one box per 4 buckets) may be NULL
-int spatial_index_launch(int b, int n, int np, const float *xyz, float4 *sorted, float *boxes, float *qboxes,
-                         hipStream_t s);
+// qboxes (one box per 4 buckets) may be NULL; src_idx / gathered (n <= 16384): see bq_index_kernel
+int spatial_index_launch(int b, int n, int np, const float *xyz, float4 *sorted, float *boxes, float *qboxes, hipStream_t s,
+                         int n_src = 0, const int *src_idx = nullptr, float *gathered = nullptr);
 
 }  // namespace epnet

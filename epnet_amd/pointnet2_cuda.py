@@ -174,6 +174,20 @@ def scene_index_build_wrapper(b, n, xyz, index):
     return 1
 
 
+@writes("new_xyz", "index")
+def scene_index_build_gathered_wrapper(b, n_src, n, xyz_src, idx, new_xyz, index):
+    """new_xyz (b,n,3) = the rows idx (b,n) of xyz_src (b,n_src,3) -- gather_points_wrapper on the (B,N,3) layout -- and the scene
+    index of those n points into `index`, one launch (include/epnet_ops.h: epnet_scene_index_build_gathered; 1024 <= n <= 16384)"""
+    px, pi, pn = dev_ptr(xyz_src, "xyz_src", _F), dev_ptr(idx, "idx", _I), dev_ptr(new_xyz, "new_xyz", _F)
+    need(xyz_src, b * n_src * 3, "xyz_src")
+    need(idx, b * n, "idx")
+    need(new_xyz, b * n * 3, "new_xyz")
+    with on_device_of(xyz_src) as s:
+        _lib.check(_lib.lib().epnet_scene_index_build_gathered(b, n_src, n, px, pi, pn, index.data_ptr(), index.numel(), s),
+                   "scene_index_build_gathered")
+    return 1
+
+
 def _index_args(index, like):
     if index is None:
         return None, 0
@@ -200,8 +214,13 @@ def sample_centres_wrapper(b, n, m, points, index, idx, new_xyz, prefix_in=None,
     epnet_sample_centres_chain): scenes whose input is known to be an unambiguous furthest-point sequence of at least m
     samples get idx = 0 .. m-1 without running the rounds -- the same result; prefix_cap = the next level's sample count
     (ties are looked for in that many rounds only; 0 = all)"""
-    pp, pi, pn = dev_ptr(points, "points", _F), dev_ptr(idx, "idx", _I), dev_ptr(new_xyz, "new_xyz", _F)
-    need(points, b * n * 3, "points"); need(idx, b * m, "idx"); need(new_xyz, b * m * 3, "new_xyz")
+    pp, pi = dev_ptr(points, "points", _F), dev_ptr(idx, "idx", _I)
+    pn = dev_ptr(new_xyz, "new_xyz", _F) if new_xyz is not None else None   # (None: indices only, chained form)
+    need(points, b * n * 3, "points"); need(idx, b * m, "idx")
+    if new_xyz is not None:
+        need(new_xyz, b * m * 3, "new_xyz")
+    elif prefix_in is None and prefix_out is None:
+        raise RuntimeError("new_xyz may be None only with prefix_in / prefix_out (epnet_sample_centres_chain)")
     px, nb = _index_args(index, points)
     temp = None if 64 <= n <= 16384 else torch.full((b, n), 1e10, dtype=_F, device=points.device)
     pt = None if temp is None else temp.data_ptr()

@@ -118,6 +118,8 @@ class SAStack:
         # levels 2.. of the pyramid sample the centres of the level above: with the chain of tie-free round counts handed from level
         # to level (epnet_sample_centres_chain) their rounds are skipped wherever the answer is known to be 0 .. m-1
         self.chain = bool(int(os.environ.get("EPNET_SA_CHAIN", "1"))) and fused_sampling
+        self.fuse_gather = bool(int(os.environ.get("EPNET_SA_FUSE_GATHER", "1")))   # centre gather inside the next level's index build
+        self._deferred = None
         # the level-1 sampling issued ahead of stage G's first kernel (both wait for the level-1 index only): its one-per-CU workgroups
         # find their registers before the wide kernels fill the CUs. 128 scenes 2.62 -> 2.57 ms, 256 scenes with every query in
         # stage G 3.52 -> 3.43; nothing once stage G starts with an LDS-staged gather (queries of level 2 in stage S: 3.21 = 3.22)
@@ -182,19 +184,33 @@ class SAStack:
             self.static_prev = [None, None]
 
     # ---- stage S: the sampling chain of one level
-    def _sample_level(self, L, cur_xyz, parity, index_built=False):
+    def _sample_level(self, L, cur_xyz, parity, index_built=False, defer_ok=False):
+        """defer_ok (the pipelined schedule, where nobody reads a level's centres before the whole chain is through): the gather of
+        this level's centres is left to the index build of the next level (epnet_scene_index_build_gathered: one dispatch for
+        both) -- every dispatch on the chain waits for wave slots beside the wide kernels of stage G"""
         b, n, m = self.batch, L["n"], L["m"]
         P = L["sets"][parity]
-        if P["index"] is not None and not index_built:
+        lvl = self.levels.index(L)
+        pending, self._deferred = self._deferred, None
+        if pending is not None and pending[1:] == (lvl - 1, parity):   # cur_xyz has not been written yet: gather + index in one
+            src_xyz, _, _ = pending
+            prev = self.levels[lvl - 1]
+            ext.scene_index_build_gathered_wrapper(b, prev["n"], n, src_xyz, prev["fps_idx"], cur_xyz, P["index"])
+        elif P["index"] is not None and not index_built:
             ext.scene_index_build_wrapper(b, n, cur_xyz, P["index"])
         if self.fused_sampling:   # FPS + gather of the centres in one kernel (epnet_sample_centres)
             if not self.fused:
                 L["xyz_t"].copy_(cur_xyz.transpose(1, 2))
             if self.chain:
-                lvl = self.levels.index(L)
                 prefix_in = self.levels[lvl - 1]["sets"][parity]["prefix"] if lvl > 0 else None
                 nxt = self.levels[lvl + 1]["m"] if lvl + 1 < len(self.levels) else 1
-                ext.sample_centres_wrapper(b, n, m, cur_xyz, P["index"], L["fps_idx"], P["new_xyz"], prefix_in, P["prefix"], nxt)
+                nxt_L = self.levels[lvl + 1] if lvl + 1 < len(self.levels) else None
+                defer = (defer_ok and self.fuse_gather and self.fused and nxt_L is not None
+                         and nxt_L["sets"][parity]["index"] is not None and 1024 <= m <= 16384)
+                ext.sample_centres_wrapper(b, n, m, cur_xyz, P["index"], L["fps_idx"], None if defer else P["new_xyz"],
+                                           prefix_in, P["prefix"], nxt)
+                if defer:
+                    self._deferred = (cur_xyz, lvl, parity)
             else:
                 ext.sample_centres_wrapper(b, n, m, cur_xyz, P["index"], L["fps_idx"], P["new_xyz"])
         else:                     # the reference module's sequence, op by op
@@ -298,7 +314,7 @@ class SAStack:
         forked.record(main)
         s_cur = xyz
         if self.s_first:   # the level-1 sampling is issued before the first kernel of stage G (which depends on the index build only)
-            s_cur = self._sample_level(first, xyz, parity, index_built=True)
+            s_cur = self._sample_level(first, xyz, parity, index_built=True, defer_ok=True)
         side.wait_event(forked)
         with torch.cuda.stream(side):
             # order inside stage G: everything of the previous batch's stage S is complete, so only "ball query
@@ -329,7 +345,7 @@ class SAStack:
             if self.with_fp:
                 self._interpolate_fp(1 - parity)
         for L in self.levels[(1 if self.s_first else 0):]:
-            s_cur = self._sample_level(L, s_cur, parity, index_built=L is first)
+            s_cur = self._sample_level(L, s_cur, parity, index_built=L is first, defer_ok=True)
         if self.with_fp:
             self._search_fp(xyz, parity)
         if self.s_query_levels:
@@ -386,7 +402,7 @@ class SAStack:
         for parity in (0, 1):
             cur = xyz
             for L in self.levels:
-                cur = self._sample_level(L, cur, parity)
+                cur = self._sample_level(L, cur, parity, defer_ok=True)
             if self.with_fp:
                 self._search_fp(xyz, parity)
             if self.s_query_levels:

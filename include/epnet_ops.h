@@ -205,6 +205,11 @@ int epnet_feature_gather_grad(int b, int c, int h, int w, int n, int align_corne
  * -------------------------------------------------------------------------------------- */
 size_t epnet_scene_index_bytes(int b, int n);
 int epnet_scene_index_build(int b, int n, const float *xyz, void *index, size_t index_bytes, epnet_stream_t stream);
+/* The index of the n points xyz_src[idx[0 .. n)] of every scene (rows of a (b, n_src, 3) cloud: the centres a sampling has just
+ * picked, pointnet2_modules.py:39-45), which are also written to gathered (b, n, 3) in that order: the centre gather of an SA level
+ * and the index build of the next level in one launch. 1024 <= n <= 16384; idx values in [0, n_src). */
+int epnet_scene_index_build_gathered(int b, int n_src, int n, const float *xyz_src, const int *idx, float *gathered, void *index,
+                                     size_t index_bytes, epnet_stream_t stream);
 /* same contract as epnet_furthest_point_sampling (sampling_gpu.cu:211-253) */
 int epnet_furthest_point_sampling_indexed(int b, int n, int m, const float *xyz, const void *index,
                                           size_t index_bytes, float *temp, int *idx, epnet_stream_t stream);
@@ -219,7 +224,8 @@ int epnet_sample_centres(int b, int n, int m, const float *xyz, const void *inde
  * (its tie-break matters among equal maxima only). prefix_in (b ints or NULL): leading rounds of the sampling that produced xyz
  * in which the maximum was unique (= the prefix_out of that call); scenes with prefix_in[b] >= m take the identity, the others
  * run the rounds. prefix_out (b ints or NULL): the same knowledge about this call's output (at least that many rounds), 0 where
- * the kernel cannot tell; ties are looked for during the first prefix_cap rounds only (<= 0: all) -- pass the next level's m. */
+ * the kernel cannot tell; ties are looked for during the first prefix_cap rounds only (<= 0: all) -- pass the next level's m.
+ * new_xyz may be NULL here (indices only: the centres then come out of epnet_scene_index_build_gathered of the next level). */
 int epnet_sample_centres_chain(int b, int n, int m, const float *xyz, const void *index, size_t index_bytes, float *temp,
                                int *idx, float *new_xyz, const int *prefix_in, int *prefix_out, int prefix_cap,
                                epnet_stream_t stream);

@@ -613,6 +613,32 @@ def test_three_nn_non_finite_coordinates(oracle, tile, monkeypatch):
     np.testing.assert_array_equal(host(d2), o_d2)
 
 
+@pytest.mark.parametrize("b,n_src,n", [(2, 16384, 4096), (3, 4096, 1024), (2, 5000, 2500), (1, 20000, 16384)])
+def test_scene_index_built_from_sampled_rows(oracle, b, n_src, n):
+    """epnet_scene_index_build_gathered: the centre gather of an SA level and the index build of the next level in one launch --
+    the rows come out as gather_points would give them, and the index answers for exactly those points (ball query and
+    sampling over it against the oracle on the gathered cloud)"""
+    from epnet_amd import pointnet2_cuda as ext
+    rng = np.random.default_rng(n)
+    src = rand_cloud(b, n_src, seed=n_src, kind="kitti")
+    idx = np.stack([rng.permutation(n_src)[:n] for _ in range(b)]).astype(np.int32)
+    idx[:, 7] = idx[:, 3]                                   # a repeated row
+    want = np.take_along_axis(src, idx[:, :, None].astype(np.int64), axis=1)
+    new_xyz = torch.full((b, n, 3), float("nan"), device=DEV)
+    index = torch.empty((ext.scene_index_bytes(b, n),), dtype=torch.uint8, device=DEV)
+    ext.scene_index_build_gathered_wrapper(b, n_src, n, dev(src), dev(idx), new_xyz, index)
+    np.testing.assert_array_equal(host(new_xyz), want)
+    m = 300
+    centres = np.ascontiguousarray(want[:, :m])
+    got = torch.empty((b, m, 24), dtype=torch.int32, device=DEV)
+    ext.ball_query_indexed_wrapper(b, n, m, 0.7, 24, dev(centres), new_xyz, index, got)
+    np.testing.assert_array_equal(host(got), oracle.ball_query(0.7, 24, want, centres))
+    fps = torch.empty((b, 200), dtype=torch.int32, device=DEV)
+    temp = torch.full((b, n), 1e10, device=DEV)
+    ext.furthest_point_sampling_indexed_wrapper(b, n, 200, new_xyz, index, temp, fps)
+    np.testing.assert_array_equal(host(fps), oracle.furthest_point_sampling(want, 200))
+
+
 def test_scene_index_is_remembered_only_on_the_packages_own_centres():
     """a scene index is remembered on the tensor object it was built from, and only for tensors this package allocated
     itself (the centres of an SA level); a caller's tensor is indexed afresh on every call"""
