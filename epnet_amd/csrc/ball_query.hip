@@ -279,8 +279,10 @@ __global__ __launch_bounds__(kIxThreads) void bq_index_kernel(int n, int np, con
         int pos[kIxPerThread];
 #pragma unroll
         for (int i = 0; i < kIxPerThread; ++i) pos[i] = s_hist[code[i]] + rank[i];   // start of the cell + rank inside it
-        const int quarter = np >> 2;  // a multiple of 64 (np is a power of two >= 2048)
-        for (int h = 0; h < 4; ++h) {
+        // a quarter of the scene per round; the 256-thread variant at most 512 points (8 KB): with 26 KB of LDS in all it still finds
+        // room on a CU that holds two 64 KB workgroups of a row gather -- at 34 KB it waited for the whole gather to drain (260 us)
+        const int quarter = kIxThreads == 256 ? min(np >> 2, 512) : np >> 2;  // a multiple of 64 (np is a power of two >= 2048)
+        for (int h = 0; h * quarter < np; ++h) {
             const int base = h * quarter;
             for (int p = q; p < quarter; p += kIxThreads)   // padding rows: never inside a ball
                 if (base + p >= n) s_stage[p] = make_float4(3.0e38f, 3.0e38f, 3.0e38f, __int_as_float(-1));
@@ -691,8 +693,8 @@ int epnet::spatial_index_launch(int b, int n, int np, const float *xyz, float4 *
                                 hipStream_t s, int n_src, const int *src_idx, float *gathered) {
     if (n <= 4096) {
         constexpr int T = 256, cells = 1 << 12;
-        // (+ the staging buffer of a quarter of the sorted scene: 8 - 16 KB here, 64 KB below)
-        const size_t stage = (np & 255) == 0 ? (size_t)(np / 4) * sizeof(float4) : 0;
+        // (+ the staging buffer of a quarter of the sorted scene, at most 512 points = 8 KB here; 64 KB below)
+        const size_t stage = (np & 255) == 0 ? (size_t)(np / 4 < 512 ? np / 4 : 512) * sizeof(float4) : 0;
         hipLaunchKernelGGL((bq_index_kernel<T, 12>), dim3(b), dim3(T), (size_t)(cells + cells / (cells / T) + 64) * sizeof(int) + stage, s,
                            n, np, xyz, sorted, boxes, qboxes, n_src, src_idx, gathered);
     } else {
