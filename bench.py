@@ -45,7 +45,7 @@ def parse():
                     help="BASELINE.json config: 2 = 16384-point scenes through the 4-level stack (the metric's configuration), "
                          "5 = dense 65536-point scenes, one level: FPS 16384, ball query r 0.5 / nsample 64, grouping C = 3 and 64")
     ap.add_argument("--points", type=int, default=None, help="points per scene (default: the config's)")
-    ap.add_argument("--kind", default="kitti", choices=["kitti", "ubox", "dup"])
+    ap.add_argument("--kind", default="kitti", choices=["kitti", "ubox", "dup", "kitti_q"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-overlap", action="store_true",
                     help="single stream: do not run ball query / grouping of level l beside the FPS of level l+1")
@@ -63,12 +63,15 @@ def parse():
     ap.add_argument("--cpu-scenes", type=int, default=None,
                     help="scenes in the cpu_baseline sample (0 = skip; default 16 for config 2, 2 for config 5)")
     ap.add_argument("--sweep", default="", help="comma list of extra batch sizes to time (reported under 'sweep')")
-    ap.add_argument("--extras", default="b1,with_fp,config5",
-                    help="further measurements reported as sub-objects of the default N = 1 line (comma list of b1, with_fp, config5; "
+    ap.add_argument("--extras", default="b1,with_fp,kinds,config5",
+                    help="further measurements reported as sub-objects of the default N = 1 line (comma list of b1, with_fp, kinds, config5; "
                          "empty = none)")
     ap.add_argument("--verify-scenes", type=int, default=1,
                     help="scenes of the timed buffers rank 0 checks against the CPU oracle after the timed loop (0 = skip; "
                          "the line then carries verified: null)")
+    ap.add_argument("--rehearsal", action="store_true",
+                    help="allow EPNET_BENCH_DEVICE / EPNET_BENCH_BACKEND (all ranks on one device, gloo instead of RCCL): the line "
+                         "then says rehearsal: true and its devices_distinct shows it; without the flag both variables are refused")
     ap.add_argument("--launch-check", action="store_true",
                     help="rehearse the N-rank launch only: the ranks rendezvous (backend EPNET_BENCH_BACKEND, default nccl), "
                          "count themselves with an all-reduce and rank 0 prints n_gpus / ranks_seen; no kernels of the path")
@@ -148,11 +151,16 @@ def cpu_baseline_multicore(kind, n_points, procs, cfg, per_proc=2):
             "sample": "%d %s scenes over %d worker processes, %.1f s wall" % (len(seeds), kind, procs, wall)}
 
 
-def verify_scene(stack, xyz, scene):
+def verify_scene(stack, xyz, scene, prev_xyz=None):
     """One scene of the buffers the timed steps left behind, checked against the CPU oracle DIRECTLY (not against another
     HIP path): every level's FPS indices and centres, both ball-query index tensors, both grouped tensors
     [xyz - centre ; features] (and, with the FP ops in the step, three_nn / three_interpolate). Integer outputs and copies
     must be identical; the interpolation is held to 1e-5. Returns the list of mismatching outputs (empty = verified).
+
+    A software-pipelined stack holds TWO batches after a step (SAStack.owners()): `xyz` is the batch the last step sampled
+    (stage S: fps_idx, its parity's centres / stage-S ball queries / FP searches), `prev_xyz` the batch it grouped (stage G:
+    the other parity's sets, the stage-G ball queries, every grouped tensor, the interpolation outputs) -- the batch of the
+    step before. prev_xyz=None: one batch replayed into both (or an unpipelined stack).
     The oracle is the checker here, outside every timed region (oracle/oracle.py header)."""
     import numpy as np
     from oracle import oracle
@@ -165,39 +173,62 @@ def verify_scene(stack, xyz, scene):
         if not ok:
             bad.append(name)
 
-    cur = xyz[scene:scene + 1].detach().cpu().numpy()
-    clouds = [cur]
+    def expected(cloud):
+        """what the reference's op sequence produces for one cloud, level by level"""
+        cur = cloud[scene:scene + 1].detach().cpu().numpy()
+        clouds, per_level = [cur], []
+        for L in stack.levels:
+            cur_t = np.ascontiguousarray(cur.transpose(0, 2, 1))
+            fps = oracle.furthest_point_sampling(cur, L["m"])
+            new_xyz = np.ascontiguousarray(oracle.gather_points(cur_t, fps).transpose(0, 2, 1))
+            bqs = [oracle.ball_query(S["radius"], S["ns"], cur, new_xyz) for S in L["scales"]]
+            per_level.append({"cur": cur, "cur_t": cur_t, "fps": fps, "new_xyz": new_xyz, "bq": bqs})
+            cur = new_xyz
+            clouds.append(cur)
+        fp = []
+        for k, F in enumerate(stack.fp_bufs if stack.with_fp else []):
+            known, unknown = clouds[len(stack.levels) - k], clouds[len(stack.levels) - k - 1]
+            d2, nn_idx = oracle.three_nn(unknown, known)
+            fp.append((d2, nn_idx))
+        return per_level, fp
+
+    s_par, g_par = stack.owners() if hasattr(stack, "owners") else (0, 0)
+    want_s = expected(xyz)
+    want_g = want_s if (prev_xyz is None or prev_xyz is xyz) else expected(prev_xyz)
+
+    def owner(parity):   # the expectation a per-parity buffer is held to
+        return want_s if parity == s_par else want_g
+
     for lvl, L in enumerate(stack.levels):
         tag = "level%d." % (lvl + 1)
-        cur_t = np.ascontiguousarray(cur.transpose(0, 2, 1))
-        fps = oracle.furthest_point_sampling(cur, L["m"])
-        new_xyz = np.ascontiguousarray(oracle.gather_points(cur_t, fps).transpose(0, 2, 1))
-        same(tag + "fps_idx", L["fps_idx"][scene:scene + 1], fps)
+        same(tag + "fps_idx", L["fps_idx"][scene:scene + 1], want_s[0][lvl]["fps"])       # written by stage S
         for k, P in enumerate(L["sets"]):
-            same(tag + "new_xyz[set %d]" % k, P["new_xyz"][scene:scene + 1], new_xyz)
+            same(tag + "new_xyz[set %d]" % k, P["new_xyz"][scene:scene + 1], owner(k)[0][lvl]["new_xyz"])
         feats = None if L["features"] is None else L["features"][scene:scene + 1].cpu().numpy()
-        for S in L["scales"]:
+        G = want_g[0][lvl]
+        for j, S in enumerate(L["scales"]):
             stag = tag + "r%g." % S["radius"]
-            bq = oracle.ball_query(S["radius"], S["ns"], cur, new_xyz)
-            for k, idx_set in enumerate(S.get("idx_sets", [S["idx"]])):   # (one per pipeline parity when the queries run in stage S)
-                same(stag + "ball_idx[set %d]" % k, idx_set[scene:scene + 1], bq)
-            want_xyz = oracle.group_points(cur_t, bq) - new_xyz.transpose(0, 2, 1)[:, :, :, None]   # pointnet2_utils.py:250-251
+            idx_sets = S.get("idx_sets", [S["idx"]])
+            for k, idx_set in enumerate(idx_sets):   # one per pipeline parity when the queries run in stage S, else stage G's own
+                want_bq = owner(k)[0][lvl]["bq"][j] if len(idx_sets) > 1 else G["bq"][j]
+                same(stag + "ball_idx[set %d]" % k, idx_set[scene:scene + 1], want_bq)
+            bq = G["bq"][j]
+            want_xyz = oracle.group_points(G["cur_t"], bq) - G["new_xyz"].transpose(0, 2, 1)[:, :, :, None]   # pointnet2_utils.py:250-251
             want_feat = None if feats is None else oracle.group_points(feats, bq)
             if stack.fused:
                 want = want_xyz if want_feat is None else np.concatenate([want_xyz, want_feat], axis=1)  # :254-257
                 same(stag + "grouped", S["grouped"][scene:scene + 1], want)
             else:
-                same(stag + "grouped_xyz", S["grouped_xyz"][scene:scene + 1], oracle.group_points(cur_t, bq))
+                same(stag + "grouped_xyz", S["grouped_xyz"][scene:scene + 1], oracle.group_points(G["cur_t"], bq))
                 if want_feat is not None:
                     same(stag + "grouped_feat", S["grouped_feat"][scene:scene + 1], want_feat)
-        cur = new_xyz
-        clouds.append(cur)
     for k, F in enumerate(stack.fp_bufs if stack.with_fp else []):
         tag = "fp%d." % (len(stack.levels) - k)
-        known, unknown = clouds[len(stack.levels) - k], clouds[len(stack.levels) - k - 1]
-        d2, nn_idx = oracle.three_nn(unknown, known)
-        same(tag + "three_nn.idx", F["idx"][scene:scene + 1], nn_idx)
-        same(tag + "three_nn.dist2", F["dist2"][scene:scene + 1], d2)
+        for q, P in enumerate(F["sets"]):           # the searches run in stage S (one set per parity)
+            d2, nn_idx = owner(q)[1][k] if len(F["sets"]) > 1 else want_s[1][k]
+            same(tag + "three_nn.idx[set %d]" % q, P["idx"][scene:scene + 1], nn_idx)
+            same(tag + "three_nn.dist2[set %d]" % q, P["dist2"][scene:scene + 1], d2)
+        d2, nn_idx = want_g[1][k]                   # the interpolation runs in stage G
         inv = (np.float32(1.0) / (np.sqrt(d2) + np.float32(1e-8))).astype(np.float32)     # pointnet2_modules.py:157-159
         weight = (inv / inv.sum(axis=2, keepdims=True)).astype(np.float32)
         want = oracle.three_interpolate(F["known_feats"][scene:scene + 1].cpu().numpy(), nn_idx, weight)
@@ -325,8 +356,10 @@ def launch_check(args):
             torch.cuda.set_device(device)
         scene_shard.init_process_group(backend, device=None if device == "cpu" else device)
     seen = int(scene_shard.sum_over_ranks(1.0, device=device))
+    idents = scene_shard.gather_over_ranks(scene_shard.device_identity(device))
     if rank == 0:
-        print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_seen": seen, "gpus_flag": args.gpus}), flush=True)
+        print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_seen": seen, "gpus_flag": args.gpus,
+                          "devices_distinct": scene_shard.distinct_devices(idents), "devices": idents}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -342,6 +375,9 @@ def main():
     scene_shard.assert_world(args.gpus)
     if args.launch_check:
         return launch_check(args)
+    if not args.rehearsal and ("EPNET_BENCH_DEVICE" in os.environ or "EPNET_BENCH_BACKEND" in os.environ):
+        raise SystemExit("EPNET_BENCH_DEVICE / EPNET_BENCH_BACKEND rehearse the N-rank path on one device: pass --rehearsal "
+                         "(a measurement line must come from one GPU per rank over RCCL)")
     import torch
     import torch.distributed as dist
 
@@ -371,26 +407,38 @@ def main():
             scene_shard.barrier()
             torch.cuda.synchronize()
 
-    def time_stack(batch, steps, warmup, cfg=None, with_fp=None, pipelined=None):
-        """returns (seconds for `steps` steps, the stack, its input)"""
+    def time_stack(batch, steps, warmup, cfg=None, with_fp=None, pipelined=None, kind=None):
+        """returns (seconds for `steps` steps, the stack, its input batches, the step function). Two DIFFERENT resident batches
+        rotate through the steps (batch A on even steps, B on odd ones): a software-pipelined step samples one of them beside
+        the grouping of the other, as it does in a loop that consumes a new batch per iteration (tools/train_rcnn.py:221-223)."""
         cfg = args.cfg if cfg is None else cfg
         with_fp = args.with_fp if with_fp is None else with_fp
         pipelined = bool(args.pipelined) if pipelined is None else pipelined
+        kind = args.kind if kind is None else kind
         points = args.points if cfg is args.cfg else cfg["n"]
         ids = scene_shard.scene_ids(batch * world, rank, world)           # round-robin shard of the global batch
-        fn = {"ubox": synth.ubox_cloud, "kitti": synth.kitti_like_cloud, "dup": synth.dup_cloud}[args.kind]
-        xyz = torch.stack([fn(points, scene_shard.scene_seed(1, i)) for i in ids]).to(dev)  # inputs resident in HBM
+        batches = [torch.stack([synth.cloud(kind, points, scene_shard.scene_seed(1 + which, i)) for i in ids]).to(dev)
+                   for which in range(2)]                                  # inputs resident in HBM
         stack = sa_stack.SAStack(batch, n=points, device=dev, with_fp=with_fp, seed=rank,
                                  npoints=cfg["npoints"], radii=cfg["radii"], nsamples=cfg["nsamples"],
                                  feat_channels=cfg["feat_channels"],
                                  overlap=not args.no_overlap, fused=not args.unfused,
                                  shared_index=not args.no_shared_index, pipelined=pipelined,
                                  fused_sampling=not args.module_sampling)
+        count = [0]
         if args.no_graph:
-            step = lambda: stack.step(xyz)
-        else:
-            stack.capture(xyz)
+            def step():
+                stack.step(batches[count[0] & 1])
+                count[0] += 1
+        elif pipelined:
+            stack.capture(batches[0], batches[1])   # the two resident input buffers ARE the two batches: no copy per step
             step = stack.replay
+        else:
+            stack.capture(batches[0])
+
+            def step():                              # every step alone: the one input buffer takes the next batch
+                stack.replay(batches[count[0] & 1])
+                count[0] += 1
         for _ in range(warmup):
             step()
         barrier()
@@ -398,30 +446,69 @@ def main():
         for _ in range(steps):
             step()
         barrier()
-        return time.perf_counter() - t0, stack, xyz
+        return time.perf_counter() - t0, stack, batches, step
 
-    elapsed, stack, xyz = time_stack(args.batch, args.steps, args.warmup)
-    stack_s_levels = stack.s_query_levels
+    def verify_stack(stack, batches, step, scenes):
+        """the buffers the timed steps left behind against the oracle, then ONE more step and the same again: the second pass
+        sees the other batch in every role (sampled / grouped), so each of the two distinct inputs is verified end to end"""
+        mism = {}
+        for which in range(2):
+            torch.cuda.synchronize()
+            if stack.pipelined and not args.no_graph:
+                s_par, g_par = stack.owners()
+                cur, prev = stack.inputs[s_par], stack.inputs[g_par]
+            else:   # the last step consumed batches[(steps - 1) & 1]; pipelined eager steps grouped the one before it
+                done = stack.replays if stack.pipelined else step_count(step)
+                cur = batches[(done - 1) & 1]
+                prev = batches[done & 1] if stack.pipelined else None
+            for s_ in scenes:
+                bad = verify_scene(stack, cur, s_, prev_xyz=prev)
+                if bad:
+                    mism["pass %d scene %d" % (which, s_)] = bad
+            step()
+        torch.cuda.synchronize()
+        return mism
+
+    def step_count(step):
+        cells = [c.cell_contents for c in (step.__closure__ or ()) if isinstance(c.cell_contents, list) and len(c.cell_contents) == 1]
+        return cells[0][0] if cells else 0
+
+    def dispersion(step, steps):
+        """per-step durations from an event pair around every step (recorded in a loop of its own, after the timed one)"""
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        evs[0].record()
+        for k in range(steps):
+            step()
+            evs[k + 1].record()
+        torch.cuda.synchronize()
+        ms = sorted(evs[k].elapsed_time(evs[k + 1]) for k in range(steps))
+        return {"ms_per_step_min": round(ms[0], 4), "ms_per_step_median": round(ms[len(ms) // 2], 4), "ms_per_step_max": round(ms[-1], 4)}
+
+    elapsed, stack, batches, step = time_stack(args.batch, args.steps, args.warmup)
+    xyz = batches[0]
+    stack_s_levels, stack_chain = stack.s_query_levels, stack.chain
     reduce_dev = dev if dist.is_initialized() and dist.get_backend() == "nccl" else "cpu"
+    elapsed_own = elapsed
     elapsed = scene_shard.max_over_ranks(elapsed, device=reduce_dev)
     points_per_step = world * args.batch * args.points
     value = points_per_step * args.steps / elapsed
     ranks_seen = int(scene_shard.sum_over_ranks(1.0, device=reduce_dev))   # the ranks the collective library saw
+    my_ms = elapsed_own / args.steps * 1e3
+    per_rank = scene_shard.gather_over_ranks({"ms_per_step": round(my_ms, 4), "device": scene_shard.device_identity(dev)})
+    devices_distinct = scene_shard.distinct_devices([r_["device"] for r_ in per_rank])
+    spread = dispersion(step, args.steps)
+    identity_share = stack.chain_identity_share()
 
     # ---- what the timed steps left in the buffers, against the oracle (rank 0, outside every timed region)
     verification = None
     if rank == 0 and args.verify_scenes > 0:
-        torch.cuda.synchronize()
         picks = sorted({0, args.batch - 1} if args.verify_scenes > 1 else {0})
         picks += [s_ for s_ in range(1, args.batch - 1)][:max(0, args.verify_scenes - len(picks))]
-        mism = {}
-        for s_ in picks:
-            bad = verify_scene(stack, stack.static_xyz if stack.static_xyz is not None else xyz, s_)
-            if bad:
-                mism[str(s_)] = bad
-        verification = {"verified": not mism, "scenes": picks, "mismatches": mism,
+        mism = verify_stack(stack, batches, step, picks)
+        verification = {"verified": not mism, "scenes": picks, "distinct_inputs": 2, "mismatches": mism,
                         "checked": "fps_idx, centres, ball-query idx and grouped tensors of all %d levels%s of the timed buffers "
-                                   "(%s) vs oracle/epnet_oracle.c: identical"
+                                   "(%s; two different resident batches alternate, each checked as the sampled and as the grouped "
+                                   "one) vs oracle/epnet_oracle.c: identical"
                                    % (len(stack.levels), " + three_nn / three_interpolate (1e-5)" if args.with_fp else "",
                                       "pipelined HIP-graph replays" if (args.pipelined and not args.no_graph) else
                                       ("HIP-graph replays" if not args.no_graph else "eager steps"))}
@@ -482,30 +569,33 @@ def main():
 
     sweep = {}
     for bsz in [int(x) for x in args.sweep.split(",") if x]:
-        e, _, _ = time_stack(bsz, args.steps, args.warmup)
+        e = time_stack(bsz, args.steps, args.warmup)[0]
         sweep[str(bsz)] = {"ms_per_step": round(e / args.steps * 1e3, 4), "points_per_s": round(bsz * args.points * args.steps / e, 1)}
 
     # ---- further lines of the same run (N = 1, default configuration only), each verified against the oracle like the
     # headline: the single-scene latency, the step with the FP ops, and BASELINE config 5
     extras = {}
     if world == 1 and args.config == 2 and not args.with_fp and args.extras:
-        del stack, xyz
+        del stack, xyz, batches, step
         torch.cuda.empty_cache()
 
-        def extra(name, batch, steps, cfg=None, with_fp=False, pipelined=None, note=""):
+        def extra(name, batch, steps, cfg=None, with_fp=False, pipelined=None, note="", kind=None, into=None):
             cfg_ = args.cfg if cfg is None else cfg
-            e, st, _x = time_stack(batch, steps, max(2, args.warmup // 2), cfg=cfg_, with_fp=with_fp, pipelined=pipelined)
+            e, st, bt, stp = time_stack(batch, steps, max(2, args.warmup // 2), cfg=cfg_, with_fp=with_fp, pipelined=pipelined, kind=kind)
             torch.cuda.synchronize()
-            bad = verify_scene(st, st.static_xyz if st.static_xyz is not None else _x, 0) if args.verify_scenes > 0 else None
+            share = st.chain_identity_share()
+            bad = verify_stack(st, bt, stp, [0]) if args.verify_scenes > 0 else None
             pts = cfg_["n"]
             nbytes = (sa_stack.sa_algorithmic_bytes(pts, cfg_["npoints"], cfg_["nsamples"], cfg_["feat_channels"])["total"]
                       + (sa_stack.fp_algorithmic_bytes()["total"] if with_fp else 0))
             rate = batch * pts * steps / e
-            extras[name] = {"scenes_per_gpu": batch, "points_per_scene": pts, "steps": steps, "ms_per_step": round(e / steps * 1e3, 4),
-                            "points_per_s": round(rate, 1), "stack_algorithmic_GBps": round(rate / pts * nbytes / 1e9, 2),
-                            "stack_hbm_frac": round(rate / pts * nbytes / 1e9 / HBM_PEAK_GBS, 6),
-                            "verified": None if bad is None else not bad, "mismatches": bad or [], "workload": note}
-            del st, _x
+            (extras if into is None else into)[name] = {
+                "scenes_per_gpu": batch, "points_per_scene": pts, "steps": steps, "ms_per_step": round(e / steps * 1e3, 4),
+                "points_per_s": round(rate, 1), "stack_algorithmic_GBps": round(rate / pts * nbytes / 1e9, 2),
+                "stack_hbm_frac": round(rate / pts * nbytes / 1e9 / HBM_PEAK_GBS, 6),
+                "verified": None if bad is None else not bad, "mismatches": bad or {}, "distinct_inputs": 2,
+                "identity_share_levels_2_up": share, "workload": note}
+            del st, bt, stp
             torch.cuda.empty_cache()
 
         names = [x for x in args.extras.split(",") if x]
@@ -515,6 +605,12 @@ def main():
         if "with_fp" in names:
             extra("with_fp", args.batch, args.steps, with_fp=True,
                   note="the headline step + the 4 three_nn + 4 three_interpolate of the FP modules (SA+FP = 88 087 040 B per scene)")
+        if "kinds" in names:   # the other input families of BASELINE.md section 3 config 2, the same pipelined 256-scene step
+            extras["kinds"] = {}
+            for kind, what in (("ubox", "uniform box (PC_AREA_SCOPE)"),
+                               ("dup", "12000 kitti-like points padded to 16384 by re-drawing rows (kitti_rcnn_dataset.py:338-342): exact twins"),
+                               ("kitti_q", "kitti-like coordinates rounded to 1e-3 m (velodyne resolution)")):
+                extra(kind, args.batch, args.steps, kind=kind, note=what, into=extras["kinds"])
         if "config5" in names:
             extra("config5", 128, max(3, args.steps // 4), cfg=sa_stack.CONFIGS[5],
                   note="BASELINE config 5: dense 65536-point kitti-like scenes, one level -- scene index, FPS 16384, ball query "
@@ -536,7 +632,8 @@ def main():
     if rank == 0:
         levels = len(args.cfg["npoints"])
         if args.config == 2:
-            shape = ("the 4-level SA op stack (4 FPS + 4 gather + 8 ball_query + 8 fused groupings [xyz - centre ; features]%s), "
+            shape = ("the 4-level SA op stack (4 samplings [FPS + centre gather; levels 2-4 nested in level 1 where tie-free] + 8 ball_query "
+                     "+ 8 fused groupings [xyz - centre ; features]%s), "
                      "pyramid 16384>4096>1024>256>64, radii [[.1,.5],[.5,1],[1,2],[2,4]], nsample [16,32], C=0/96/256/512"
                      % (" + 4 three_nn + 4 three_interpolate" if args.with_fp else ""))
         else:
@@ -560,8 +657,15 @@ def main():
             "roofline": roofline, "roofline_hbm_bound": roofline_hbm, "kernels": kernels, "cpu_baseline": cpu,
             "cpu_baseline_multicore": cpu_multi,
             "verified": None if verification is None else verification["verified"], "verification": verification,
-            "ranks_seen": ranks_seen,
+            "ranks_seen": ranks_seen, "devices_distinct": devices_distinct, "rehearsal": bool(args.rehearsal),
+            "per_rank_ms_per_step": {"min": min(r_["ms_per_step"] for r_ in per_rank), "max": max(r_["ms_per_step"] for r_ in per_rank),
+                                     "ranks": [r_["ms_per_step"] for r_ in per_rank]},
+            "devices": [r_["device"] for r_ in per_rank],
+            "sampling_chain": {"enabled": bool(stack_chain), "identity_share_levels_2_up": identity_share,
+                               "note": "levels 2.. sample the centres of the level above: a scene whose tie-free prefix covers the "
+                                       "level's sample count takes idx = 0..m-1 without running rounds (epnet_sample_centres_chain)"},
         }
+        line.update(spread)
         if world > 1:
             line["cpu_baseline_note"] = "the CPU baseline is timed in the N = 1 run only (rank 0 there has the host to itself)"
         if sweep:

@@ -191,7 +191,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1,
                     help="ranks (one per GPU); without a torch.distributed.run environment the ranks are started as child processes")
     ap.add_argument("--launch-check", action="store_true", help="rehearse the N-rank launch only (see bench.py)")
+    ap.add_argument("--rehearsal", action="store_true",
+                    help="allow EPNET_BENCH_DEVICE / EPNET_BENCH_BACKEND (all ranks on one device, gloo): see bench.py")
     args = ap.parse_args()
+    if args.infer and args.image:
+        ap.error("--infer times the point-stream RPN stage; the two-stream backbone (--image) is timed by the training step only")
     from epnet_amd import scene_shard
     code = scene_shard.launch_or_continue(args.gpus, os.path.abspath(__file__), sys.argv[1:])
     if code is not None:
@@ -200,6 +204,8 @@ def main():
     if args.launch_check:
         import bench
         return bench.launch_check(args)
+    if not args.rehearsal and ("EPNET_BENCH_DEVICE" in os.environ or "EPNET_BENCH_BACKEND" in os.environ):
+        raise SystemExit("EPNET_BENCH_DEVICE / EPNET_BENCH_BACKEND rehearse the N-rank path on one device: pass --rehearsal")
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -274,10 +280,32 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    elapsed_own = elapsed
     if world > 1:
         t = torch.tensor([elapsed], device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
+    per_rank = scene_shard.gather_over_ranks({"ms_per_step": round(elapsed_own / args.steps * 1e3, 3),
+                                              "device": scene_shard.device_identity(device)})
+    # the gradient exchange on its own: one all-reduce of a buffer as large as all gradients (DDP sends the same bytes in buckets,
+    # overlapped with backward -- this is the un-overlapped cost it hides)
+    allreduce = None
+    if world > 1:
+        n_grad = sum(p.numel() for p in model.parameters() if p.requires_grad)
+        flat = torch.zeros((n_grad,), dtype=torch.float32, device=device)
+        for _ in range(2):
+            dist.all_reduce(flat)
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a0.record()
+        for _ in range(5):
+            dist.all_reduce(flat)
+        a1.record()
+        torch.cuda.synchronize()
+        ar_ms = a0.elapsed_time(a1) / 5
+        allreduce = {"bytes": n_grad * 4, "ms_alone": round(ar_ms, 3), "backend": dist.get_backend(),
+                     "bus_GBps": round(2 * (world - 1) / world * n_grad * 4 / (ar_ms * 1e-3) / 1e9, 2)}
+        del flat
     # ---- share of the step spent inside this package's operators: an instrumented pass with a HIP event pair around every
     # call into the three extension stand-ins (on the stream the call launches on), against the GPU time of the same steps
     ops_share = None
@@ -327,6 +355,10 @@ def main():
                           "scenes_per_s": round(world * args.batch * args.steps / elapsed, 2),
                           "phase_ms": {k: round(v / args.steps, 3) for k, v in phases.items()},
                           "parameters": n_param, "grad_allreduce_MB": round(n_param * 4 / 1e6, 1) if world > 1 else 0,
+                          "grad_allreduce": allreduce, "devices_distinct": scene_shard.distinct_devices([r_["device"] for r_ in per_rank]),
+                          "devices": [r_["device"] for r_ in per_rank], "rehearsal": bool(args.rehearsal),
+                          "per_rank_ms_per_step": {"min": min(r_["ms_per_step"] for r_ in per_rank),
+                                                   "max": max(r_["ms_per_step"] for r_ in per_rank)},
                           "loss": last, "data": "synthetic", "dtype": "f32",
                           "note": "phase_ms from HIP events (phases are host-serialised by the two syncs of the target layer); "
                                   "dense layers are stock PyTorch-ROCm, geometry ops this package's HIP kernels"}))

@@ -16,8 +16,12 @@ The stack has two stages with very different machine behaviour:
   S  the sampling chain (scene index -> FPS -> gather, level after level): a strictly serial, latency-bound
      chain of one-workgroup-per-scene kernels that needs almost no LDS and no bandwidth;
   G  ball query + grouping of every level: wide, bandwidth-bound, depends on S only through the centres.
-``pipelined=True`` runs S of batch k beside G of batch k-1 (double-buffered centres / indices), so that in
-steady state a step costs max(S, G) instead of S(level 1) + G.
+``pipelined=True`` runs S of batch k beside G of batch k-1 (double-buffered input clouds / centres / indices), so
+that in steady state a step costs max(S, G) instead of S(level 1) + G. Consecutive steps consume DIFFERENT batches (the
+reference's loop does: tools/train_rcnn.py:221-223, lib/net/train_functions.py): the input cloud has one resident buffer
+per pipeline parity (``inputs[0 / 1]``); step k samples ``inputs[k & 1]`` and groups ``inputs[1 - (k & 1)]``, the batch of
+step k-1, whose results are therefore complete once step k is (``SAStack.owners()`` says which buffer belongs to which
+batch).
 """
 import os
 
@@ -179,9 +183,42 @@ class SAStack:
                 })
         self.graphs = []
         self.replays = 0
-        self.static_xyz = None
-        if pipelined:  # the centres of both parities, one per "previous batch"
-            self.static_prev = [None, None]
+        # the resident input clouds a captured graph reads: one per pipeline parity (one when every step stands alone)
+        self.inputs = []
+        self._prev_xyz = None   # eager pipelined steps: the cloud of the step before (stage G of the next step reads it)
+
+    @property
+    def static_xyz(self):
+        """the input buffer of an unpipelined capture (a pipelined one has two: self.inputs)"""
+        if self.pipelined and self.inputs:
+            raise AttributeError("a pipelined stack has one input buffer per parity: use stack.inputs / stack.input_buffer()")
+        return self.inputs[0] if self.inputs else None
+
+    def input_buffer(self, step=None):
+        """the resident cloud stage S of step `step` (default: the next one) reads -- the buffer a loader fills (stream-ordered
+        behind the previous replay, whose stage G was the last reader of its old contents) instead of handing replay() a copy"""
+        step = self.replays if step is None else step
+        return self.inputs[step % len(self.inputs)]
+
+    def owners(self):
+        """After `replays` >= 1 steps of a pipelined stack: (parity sampled by the last step, parity it grouped). Buffers written
+        by stage S (fps_idx, sets[p], the idx_sets[p] of the levels in s_query_levels, the FP search sets[p]) hold the batch
+        of the LAST step; buffers written by stage G (grouped tensors, the single idx tensors of the other levels, the
+        interpolation outputs) and the other parity's sets hold the batch of the step BEFORE it."""
+        p = (self.replays - 1) & 1 if self.pipelined else 0
+        return p, (1 - p if self.pipelined else 0)
+
+    def chain_identity_share(self, parity=None):
+        """per level 2.. of the pyramid: the share of scenes whose sampling took the identity (the level above reported a tie-free
+        prefix at least as long as this level's sample count) in the last step that sampled into set `parity`"""
+        if not self.chain:
+            return None
+        parity = self.owners()[0] if parity is None else parity
+        out = []
+        for lvl in range(1, len(self.levels)):
+            known = self.levels[lvl - 1]["sets"][parity if self.pipelined else 0]["prefix"]
+            out.append(round(float((known >= self.levels[lvl]["m"]).float().mean().item()), 4))
+        return out
 
     # ---- stage S: the sampling chain of one level
     def _sample_level(self, L, cur_xyz, parity, index_built=False, defer_ok=False):
@@ -396,11 +433,11 @@ class SAStack:
         self._search_fp(xyz, parity)
         self._interpolate_fp(parity)
 
-    def _prime(self, xyz):
-        """before the first pipelined step: stage S of `xyz` into BOTH sets, so that the first steps' stage G (the
-        "previous batch") reads valid centres and indices, never uninitialised memory"""
+    def _prime(self, clouds):
+        """before the first pipelined step: stage S of clouds[p] into set p for BOTH parities, so that the first step's stage G
+        (the "previous batch" = clouds[1]) reads valid centres and indices, never uninitialised memory"""
         for parity in (0, 1):
-            cur = xyz
+            xyz = cur = clouds[parity]
             for L in self.levels:
                 cur = self._sample_level(L, cur, parity, defer_ok=True)
             if self.with_fp:
@@ -410,20 +447,23 @@ class SAStack:
 
     def _step_eager(self, k):
         if self.pipelined:
-            self.run_pipelined(self.static_xyz, self.static_xyz, k)
+            self.run_pipelined(self.inputs[k & 1], self.inputs[1 - (k & 1)], k)
         else:
-            self.run(self.static_xyz)
+            self.run(self.inputs[0])
 
-    def capture(self, xyz):
-        """capture the step into HIP graph(s) (torch.cuda.CUDAGraph); replay with self.replay(). Pipelined:
-        two graphs, one per parity, replayed alternately."""
-        self.static_xyz = xyz.clone()
+    def capture(self, xyz, xyz_other=None):
+        """capture the step into HIP graph(s) (torch.cuda.CUDAGraph); replay with self.replay(). Pipelined: two graphs, one per
+        parity, replayed alternately; graph p samples inputs[p] and groups inputs[1 - p]. `xyz` fills inputs[0], `xyz_other`
+        (default: the same cloud) inputs[1]: the batch the FIRST replay's grouping stage sees as "the step before"."""
+        self.inputs = [xyz.clone()]
+        if self.pipelined:
+            self.inputs.append((xyz if xyz_other is None else xyz_other).clone())
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         period = 1
         with torch.cuda.stream(s):
             if self.pipelined:
-                self._prime(self.static_xyz)
+                self._prime(self.inputs)
         if self.pipelined:
             period = 2   # one graph per parity
         with torch.cuda.stream(s):
@@ -441,19 +481,24 @@ class SAStack:
         return self.graphs[0]
 
     def replay(self, xyz=None):
+        """one step from the captured graph(s). `xyz`: the batch of THIS step, copied into the input buffer of the step's parity
+        (stream-ordered behind the previous replay, the last reader of that buffer's old contents); None: the caller has
+        filled stack.input_buffer() itself, or replays the resident batches again (the bench)."""
         if xyz is not None:
-            self.static_xyz.copy_(xyz)
+            self.input_buffer().copy_(xyz)
         self.graphs[self.replays % len(self.graphs)].replay()
         self.replays += 1
 
     def step(self, xyz):
-        """eager (no graph) step"""
+        """eager (no graph) step on the caller's own tensor. Pipelined: stage S of `xyz` beside stage G of the cloud handed to
+        the step before, which the caller therefore leaves untouched until this step has been issued (stream order does the rest)."""
         if self.pipelined:
-            if self.static_xyz is None:
-                self.static_xyz = xyz
-                self._prime(xyz)
+            if self._prev_xyz is None:
+                self._prime([xyz, xyz])
+                self._prev_xyz = xyz
                 self.replays = 0
-            self.run_pipelined(xyz, self.static_xyz, self.replays & 1)
+            self.run_pipelined(xyz, self._prev_xyz, self.replays & 1)
+            self._prev_xyz = xyz
             self.replays += 1
         else:
             self.run(xyz)

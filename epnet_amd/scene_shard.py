@@ -120,3 +120,37 @@ def sum_over_ranks(value, device="cpu"):
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def device_identity(device=None):
+    """a string that names the physical device this rank computes on: host + PCI address / UUID of the torch device (a rank
+    without a GPU -- the gloo rehearsal -- names host + process, so that such ranks never pass for distinct GPUs)"""
+    import socket
+    host = socket.gethostname()
+    if device is None or str(device) == "cpu":
+        return "%s/cpu/pid%d" % (host, os.getpid())
+    import torch
+    prop = torch.cuda.get_device_properties(device)
+    parts = []
+    for name in ("uuid", "pci_domain_id", "pci_bus_id", "pci_device_id"):
+        v = getattr(prop, name, None)
+        if v is not None:
+            parts.append("%s=%s" % (name, v))
+    if not parts:   # no identifying property on this build: the device ordinal is all there is
+        parts.append("ordinal=%d" % torch.device(device).index)
+    return "%s/gpu/%s" % (host, ",".join(parts))
+
+
+def gather_over_ranks(obj):
+    """every rank's python object, in rank order (a list of one for a single process)"""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
+def distinct_devices(identities):
+    """how many different physical GPUs a list of device_identity() strings names (CPU ranks count as none)"""
+    return len({i for i in identities if "/gpu/" in i})

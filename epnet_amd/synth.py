@@ -82,10 +82,22 @@ def dup_cloud(n, seed=0, unique=12000):
     return torch.cat([base, base[extra]], dim=0).contiguous()
 
 
+def kitti_q_cloud(n, seed=0):
+    """KITTI-like coordinates rounded to 1e-3 m, the resolution velodyne .bin files carry: decimal-quantised coordinates
+    make equal fp32 distances (FPS ties) far likelier than the continuous generator does"""
+    return (torch.round(kitti_like_cloud(n, seed) * 1000.0) / 1000.0).contiguous()
+
+
+KINDS = {"ubox": ubox_cloud, "kitti": kitti_like_cloud, "dup": dup_cloud, "kitti_q": kitti_q_cloud}
+
+
+def cloud(kind, n, seed=0):
+    return KINDS[kind](n, seed)
+
+
 def scenes(kind, batch, n, seed=0):
     """(batch, n, 3) stack of independent scenes; scene i uses seed + i"""
-    fn = {"ubox": ubox_cloud, "kitti": kitti_like_cloud, "dup": dup_cloud}[kind]
-    return torch.stack([fn(n, seed + i) for i in range(batch)], dim=0).contiguous()
+    return torch.stack([KINDS[kind](n, seed + i) for i in range(batch)], dim=0).contiguous()
 
 
 def proposal_boxes(num, seed=0, num_objects=40, jitter=1.0):

@@ -40,9 +40,26 @@ def test_gpus_flag_starts_that_many_ranks(script):
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["gpus_flag"] == 2
+    # every rank reports the device it computes on; CPU (gloo) ranks never pass for distinct GPUs
+    assert len(line["devices"]) == 2 and len(set(line["devices"])) == 2 and line["devices_distinct"] == 0
 
 
 @pytest.mark.timeout(120)
 def test_world_contradicting_flag_is_refused():
     r = _run("bench.py", ["--gpus", "4", "--launch-check"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "--gpus 4" in (r.stderr + r.stdout)
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("script", ["bench.py", "bench_step.py"])
+def test_rehearsal_switches_need_the_rehearsal_flag(script):
+    """EPNET_BENCH_DEVICE can put every rank on one GPU: a measurement run refuses it (before touching any device)"""
+    r = _run(script, [], {"EPNET_BENCH_DEVICE": "0"})
+    assert r.returncode != 0 and "--rehearsal" in (r.stderr + r.stdout)
+
+
+def test_distinct_devices_counts_gpus_not_ranks():
+    from epnet_amd import scene_shard as ss
+    ids = ["h/gpu/uuid=a", "h/gpu/uuid=a", "h/gpu/uuid=b", "h/cpu/pid7"]
+    assert ss.distinct_devices(ids) == 2
+    assert ss.gather_over_ranks("x") == ["x"] and "/cpu/" in ss.device_identity("cpu")

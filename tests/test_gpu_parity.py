@@ -1133,10 +1133,10 @@ def test_the_benchs_own_configuration_against_the_oracle(oracle, with_fp, kind, 
         stack.replay()
     torch.cuda.synchronize()
     for scene in range(b):
-        assert bench.verify_scene(stack, stack.static_xyz, scene) == []
+        assert bench.verify_scene(stack, stack.inputs[0], scene) == []
     # the checker does notice a wrong buffer
     stack.levels[1]["scales"][0]["idx"][0, 5, 3] += 1
-    assert bench.verify_scene(stack, stack.static_xyz, 0) == ["level2.r0.5.ball_idx[set 0]"]
+    assert bench.verify_scene(stack, stack.inputs[0], 0) == ["level2.r0.5.ball_idx[set 0]"]
 
 
 def test_config5_stack_against_the_oracle(oracle):
@@ -1158,7 +1158,7 @@ def test_config5_stack_against_the_oracle(oracle):
     for _ in range(3):
         stack.replay()
     torch.cuda.synchronize()
-    assert bench.verify_scene(stack, stack.static_xyz, 1) == []
+    assert bench.verify_scene(stack, stack.inputs[0], 1) == []
 
 
 @pytest.mark.parametrize("b,c,n,m,ns", [(2, 64, 65536, 2048, 64), (1, 16, 40000, 4000, 20), (2, 128, 20000, 700, 32), (1, 20, 17000, 2001, 12)])
