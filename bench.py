@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None,
-                    help="scenes per GPU per step (default 256 for config 2, 128 for config 5; EPNET_BENCH_BATCH overrides)")
+                    help="scenes per GPU per step (default 256; EPNET_BENCH_BATCH overrides)")
     ap.add_argument("--config", type=int, default=2, choices=[2, 5],
                     help="BASELINE.json config: 2 = 16384-point scenes through the 4-level stack (the metric's configuration), "
                          "5 = dense 65536-point scenes, one level: FPS 16384, ball query r 0.5 / nsample 64, grouping C = 3 and 64")
@@ -81,7 +81,7 @@ def parse():
     if args.points is None:
         args.points = args.cfg["n"]
     if args.batch is None:
-        args.batch = int(os.environ.get("EPNET_BENCH_BATCH", "256" if args.config == 2 else "128"))
+        args.batch = int(os.environ.get("EPNET_BENCH_BATCH", "256"))   # (config 5: 80 GB of resident buffers; one sampling workgroup per CU)
     if args.cpu_scenes is None:
         args.cpu_scenes = int(os.environ.get("EPNET_BENCH_CPU_SCENES", "16" if args.config == 2 else "2"))
     if args.with_fp and args.config != 2:
@@ -286,7 +286,7 @@ def op_family(name, head):
     if name.startswith("gather_points_w"):
         b, c, n, m = head[:4]
         return "gather", b * (m * 4 + c * n * 4 + c * m * 4)
-    if name.startswith("ball_query_multi"):  # all scales of the level in one launch: the bytes of each query
+    if name.startswith(("ball_query_multi", "ball_query_ordered")):  # all scales of the level in one launch: the bytes of each query
         b, n, m, radii, nss = head[:5]
         return ("ball_query N=%d M=%d r=%s ns=%s" % (n, m, "+".join("%g" % r for r in radii), "+".join(str(x) for x in nss)),
                 sum(b * (n * 12 + m * 12 + m * ns * 4) for ns in nss))
@@ -612,7 +612,7 @@ def main():
                                ("kitti_q", "kitti-like coordinates rounded to 1e-3 m (velodyne resolution)")):
                 extra(kind, args.batch, args.steps, kind=kind, note=what, into=extras["kinds"])
         if "config5" in names:
-            extra("config5", 128, max(3, args.steps // 4), cfg=sa_stack.CONFIGS[5],
+            extra("config5", 256, max(3, args.steps // 4), cfg=sa_stack.CONFIGS[5],
                   note="BASELINE config 5: dense 65536-point kitti-like scenes, one level -- scene index, FPS 16384, ball query "
                        "r 0.5 / nsample 64, grouping of coordinates and 64 feature channels (python bench.py --config 5 for the full line)")
 

@@ -58,6 +58,7 @@ SIGNATURES = {
     "epnet_sample_centres_chain": (_i, [_i, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "epnet_group_concat_multi": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "epnet_ball_query_indexed_multi": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "epnet_ball_query_ordered": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp, _vp]),
     "epnet_three_nn_indexed": (_i, [_i, _i, _i, _vp, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp]),
     "epnet_ball_query_indexed": (_i, [_i, _i, _i, _f, _i, _vp, _vp, _vp, _sz, _vp, _vp]),
     "epnet_boxes_overlap_bev": (_i, [_i, _vp, _i, _vp, _vp, _vp]),

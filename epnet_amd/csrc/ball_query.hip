@@ -492,24 +492,35 @@ struct BqScales {
     int *idx[K];   // (B, M, nsample[k])
 };
 
+// order (or NULL) / npc: the scene index of the CENTRES (npc entries per scene, the m real ones first): wave w then serves the
+// w-th centre in that spatial order instead of centre w -- consecutive waves walk the same quads, buckets and rows, which are
+// still in the CU's L1 / the XCD's L2 from the neighbour (FPS order scatters consecutive centres over the whole scene)
 template <int DPL, int K>
 __global__ __launch_bounds__(kQThreads) void bq_query_kernel(int np, int m, BqScales<K> sc,
                                                              const float *__restrict__ new_xyz,
                                                              const float4 *__restrict__ sorted,
                                                              const float *__restrict__ boxes,
-                                                             const float *__restrict__ qboxes) {
+                                                             const float *__restrict__ qboxes,
+                                                             const float4 *__restrict__ order, int npc) {
     __shared__ unsigned s_bits[kQThreads / 64][64 * DPL];
     __shared__ int s_quads[kQThreads / 64][64];
     __shared__ int s_hits[kQThreads / 64][K][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int bs = blockIdx.y;
-    const int ci = blockIdx.x * (kQThreads / 64) + wave;
+    int ci = blockIdx.x * (kQThreads / 64) + wave;
     if (ci >= m) return;  // wave-uniform; no block-level barrier below
     sorted += (size_t)bs * np;
     boxes += (size_t)bs * (np / 64) * 6;
     qboxes += (size_t)bs * (np / 256) * 6;
-    const float *c = new_xyz + ((size_t)bs * m + ci) * 3;
-    const float cx = c[0], cy = c[1], cz = c[2];
+    float cx, cy, cz;
+    if (order) {
+        const float4 e = order[(size_t)bs * npc + ci];
+        ci = __float_as_int(e.w);
+        cx = e.x; cy = e.y; cz = e.z;
+    } else {
+        const float *c = new_xyz + ((size_t)bs * m + ci) * 3;
+        cx = c[0]; cy = c[1]; cz = c[2];
+    }
     float r2max = sc.r2[0];
 #pragma unroll
     for (int k = 1; k < K; ++k) r2max = fmaxf(r2max, sc.r2[k]);
@@ -549,7 +560,8 @@ __global__ __launch_bounds__(kQThreads) void bq_query2_kernel(int np, int m, BqS
                                                               const float *__restrict__ new_xyz,
                                                               const float4 *__restrict__ sorted,
                                                               const float *__restrict__ boxes,
-                                                              const float *__restrict__ qboxes) {
+                                                              const float *__restrict__ qboxes,
+                                                              const float4 *__restrict__ order, int npc) {
     __shared__ unsigned s_bits[kQThreads / 64][64 * DPL];
     __shared__ int s_quads[kQThreads / 64][2][64];
     __shared__ int s_hits[kQThreads / 64][2][K][64];
@@ -561,9 +573,20 @@ __global__ __launch_bounds__(kQThreads) void bq_query2_kernel(int np, int m, BqS
     sorted += (size_t)bs * np;
     boxes += (size_t)bs * (np / 64) * 6;
     qboxes += (size_t)bs * (np / 256) * 6;
-    const float *c0 = new_xyz + ((size_t)bs * m + ci0) * 3;
-    const float *c1 = two ? c0 + 3 : c0;  // an odd tail repeats centre 0 (its second copy is never written)
-    const float ax = c0[0], ay = c0[1], az = c0[2], bx_ = c1[0], by_ = c1[1], bz_ = c1[2];
+    float ax, ay, az, bx_, by_, bz_;
+    int out0 = ci0, out1 = ci0 + 1;   // the rows of idx the two centres write
+    if (order) {   // the two neighbours in the centres' spatial order (see bq_query_kernel): they mostly want the same rows
+        const float4 e0 = order[(size_t)bs * npc + ci0], e1 = order[(size_t)bs * npc + ci0 + (two ? 1 : 0)];
+        ax = e0.x; ay = e0.y; az = e0.z;
+        bx_ = e1.x; by_ = e1.y; bz_ = e1.z;
+        out0 = __float_as_int(e0.w);
+        out1 = __float_as_int(e1.w);
+    } else {
+        const float *c0 = new_xyz + ((size_t)bs * m + ci0) * 3;
+        const float *c1 = two ? c0 + 3 : c0;  // an odd tail repeats centre 0 (its second copy is never written)
+        ax = c0[0]; ay = c0[1]; az = c0[2];
+        bx_ = c1[0]; by_ = c1[1]; bz_ = c1[2];
+    }
     const int half = lane >> 5;  // which centre this lane serves in the bucket-box stage
     const float hx = half ? bx_ : ax, hy = half ? by_ : ay, hz = half ? bz_ : az;
     float r2max = sc.r2[0];
@@ -651,7 +674,7 @@ __global__ __launch_bounds__(kQThreads) void bq_query2_kernel(int np, int m, BqS
         const float cx = e ? bx_ : ax, cy = e ? by_ : ay, cz = e ? bz_ : az;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            int *out = sc.idx[k] + ((size_t)bs * m + ci0 + e) * sc.nsample[k];
+            int *out = sc.idx[k] + ((size_t)bs * m + (e ? out1 : out0)) * sc.nsample[k];
             if (cnt[e][k] <= 64)
                 bq_emit_list(lane, s_hits[wave][e][k], cnt[e][k], sc.nsample[k], out);
             else
@@ -708,7 +731,7 @@ int epnet::spatial_index_launch(int b, int n, int np, const float *xyz, float4 *
 
 template <int K>
 static int bq_query_launch(int b, int np, int m, const BqScales<K> &sc, const float *new_xyz, const float4 *sorted,
-                           hipStream_t s) {
+                           hipStream_t s, const float4 *order = nullptr, int npc = 0) {
     const float *boxes = (const float *)(sorted + (size_t)b * np);
     const float *qboxes = boxes + (size_t)b * (np / 64) * 6;
     // enough centres to fill the chip: two per wave (half the latency per centre); EPNET_BQ_PAIR=0/1 forces either
@@ -717,7 +740,7 @@ static int bq_query_launch(int b, int np, int m, const BqScales<K> &sc, const fl
     const bool pair = pair_env >= 0 ? pair_env != 0 : (long long)b * m >= 65536;
     if (pair) {
         dim3 grid(div_up(div_up(m, 2), kQThreads / 64), b);
-#define EPNET_BQ2(D_) hipLaunchKernelGGL((bq_query2_kernel<D_, K>), grid, dim3(kQThreads), 0, s, np, m, sc, new_xyz, sorted, boxes, qboxes)
+#define EPNET_BQ2(D_) hipLaunchKernelGGL((bq_query2_kernel<D_, K>), grid, dim3(kQThreads), 0, s, np, m, sc, new_xyz, sorted, boxes, qboxes, order, npc)
         switch (np / 2048) {
             case 1: EPNET_BQ2(1); break;
             case 2: EPNET_BQ2(2); break;
@@ -730,7 +753,7 @@ static int bq_query_launch(int b, int np, int m, const BqScales<K> &sc, const fl
         return check_launch("ball_query query");
     }
     dim3 grid(div_up(m, kQThreads / 64), b);
-#define EPNET_BQ(D_) hipLaunchKernelGGL((bq_query_kernel<D_, K>), grid, dim3(kQThreads), 0, s, np, m, sc, new_xyz, sorted, boxes, qboxes)
+#define EPNET_BQ(D_) hipLaunchKernelGGL((bq_query_kernel<D_, K>), grid, dim3(kQThreads), 0, s, np, m, sc, new_xyz, sorted, boxes, qboxes, order, npc)
     switch (np / 2048) {
         case 1: EPNET_BQ(1); break;
         case 2: EPNET_BQ(2); break;
@@ -817,6 +840,40 @@ extern "C" int epnet_ball_query_indexed_multi(int b, int n, int m, int nscales, 
         sc.idx[k] = idx[k];
     }
     return bq_query_launch<2>(b, scene_index_np(n), m, sc, new_xyz, (const float4 *)index, (hipStream_t)stream);
+}
+
+// the nscales (1 or 2) ball queries of a level with the centres served in THEIR spatial order: centre_index is the scene index of
+// the m centres (new_xyz = the cloud it was built from, in that order). Same results as epnet_ball_query_indexed_multi.
+extern "C" int epnet_ball_query_ordered(int b, int n, int m, int nscales, const float *radii, const int *nsamples,
+                                        const float *new_xyz, const float *xyz, const void *index, size_t index_bytes,
+                                        const void *centre_index, size_t centre_index_bytes, int *const *idx,
+                                        epnet_stream_t stream) {
+    EPNET_REQUIRE(nscales >= 0 && (nscales == 0 || (radii && nsamples && idx)));
+    const size_t need = scene_index_bytes(b, n), need_c = scene_index_bytes(b, m);
+    bool ordered = (nscales == 1 || nscales == 2) && need != 0 && need_c != 0 && index && centre_index && m > 0;
+    for (int k = 0; ordered && k < nscales; ++k) ordered = nsamples[k] > 0 && idx[k] != nullptr;
+    // what the order buys is cache hits on the point rows: nothing up to 16384 points (the scene's rows stay in L2 whatever the order:
+    // 256 scenes, 16384 x 4096: 0.458 = 0.455 ms; 4096 x 1024: 0.108 -> 0.125), 31 % at 65536 (6.68 -> 4.58 ms). EPNET_BQ_ORDERED=0/1 forces.
+    const char *force = getenv("EPNET_BQ_ORDERED");
+    if (force ? atoi(force) == 0 : n <= 16384) ordered = false;
+    if (!ordered) return epnet_ball_query_indexed_multi(b, n, m, nscales, radii, nsamples, new_xyz, xyz, index, index_bytes, idx, stream);
+    if (index_bytes < need || centre_index_bytes < need_c) return EPNET_ENOMEM;
+    EPNET_REQUIRE(b <= 65535);
+    const int np = scene_index_np(n), npc = scene_index_np(m);
+    if (nscales == 1) {
+        BqScales<1> sc;
+        sc.r2[0] = radii[0] * radii[0];  // ball_query_gpu.cu:23
+        sc.nsample[0] = nsamples[0];
+        sc.idx[0] = idx[0];
+        return bq_query_launch<1>(b, np, m, sc, new_xyz, (const float4 *)index, (hipStream_t)stream, (const float4 *)centre_index, npc);
+    }
+    BqScales<2> sc;
+    for (int k = 0; k < 2; ++k) {
+        sc.r2[k] = radii[k] * radii[k];
+        sc.nsample[k] = nsamples[k];
+        sc.idx[k] = idx[k];
+    }
+    return bq_query_launch<2>(b, np, m, sc, new_xyz, (const float4 *)index, (hipStream_t)stream, (const float4 *)centre_index, npc);
 }
 
 extern "C" size_t epnet_ball_query_workspace_bytes(int b, int n, int m) {

@@ -460,9 +460,14 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
     unsigned racc = 0xFFFFFFFFu;  // != ~0 in the lanes that publish
     float xa = 0.f, ya = 0.f, za = 0.f;
     int kb = 1;  // key slot of the round = it % 3
-    // the first round whose maximum is NOT unique (several points at the maximum running distance: the reference's tie-break
-    // decides): up to that round the sequence of samples is a property of the coordinates alone (see epnet_sample_centres_chain)
-    bool wave_multi = false;  // several points of this wave hold its maximum
+    // the first round in which the reference's tie-break decides WHICH COORDINATES are sampled: several points at the maximum
+    // running distance that are not all exact twins of one another (or a maximum of zero: every point coincides with a sample).
+    // Up to that round the sequence of sampled coordinates is a property of the coordinates alone (epnet_sample_centres_chain).
+    // Exact twins -- the reference's loader pads short scenes by re-drawing rows, kitti_rcnn_dataset.py:338-342 -- tie at the
+    // round one of them is picked, harmlessly: the others sit at distance 0 from then on and cannot be sampled while the
+    // maximum is positive.
+    unsigned long long holder_mask = 0ull;  // lanes that publish this wave's maximum
+    unsigned long long multi_mask = 0ull;   // lanes holding it in several of their slots with DIFFERENT coordinates
     int tied_v = 0x7fffffff;  // wave-uniform, kept scalar
     // one round; kTies: also look for a second holder of the round's maximum (only the rounds a later level can ask about pay
     // for that: the two instantiations of the body are run one after the other)
@@ -504,6 +509,7 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
             unsigned cand = fold_parts<PPT>(__ballot(bm == wbest));
             racc = 0xFFFFFFFFu;
             hbuckets = 0ull;
+            bool mixed = false;
             do {
                 const int j = (int)__builtin_ctz(cand);
                 cand &= cand - 1u;
@@ -513,20 +519,22 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
                 __builtin_amdgcn_sched_barrier(0);  // one GPR-index window for the four slot registers
                 const unsigned r = tj == wbest ? ((rw >> ((j & 1) << 4)) & 0xFFFFu) : 0xFFFFFFFFu;
                 if (r != 0xFFFFFFFFu) hbuckets |= 1ull << ((lane & ~(PPT - 1)) | j);  // summary lane of (slot j, my part)
+                if (kTies)   // a second held slot of this lane with other coordinates than the first (equality is transitive)
+                    mixed = mixed || (r != 0xFFFFFFFFu && racc != 0xFFFFFFFFu && (xj != xa || yj != ya || zj != za));
                 const bool take = r < racc;  // a lane holding the maximum in two of its slots keeps the smaller rank
                 racc = take ? r : racc;
                 xa = take ? xj : xa;
                 ya = take ? yj : ya;
                 za = take ? zj : za;
             } while (cand);
-            if (kTies) {
-                // (hbuckets has one bit per slot in which the lane holds the maximum)
-                const unsigned long long holders = __ballot(hbuckets != 0ull);
-                wave_multi = (holders & (holders - 1ull)) != 0ull || __ballot((hbuckets & (hbuckets - 1ull)) != 0ull) != 0ull;
-            }
             if (wbest == kNeg1) {  // a wave of padding only
                 racc = 0xFFFFFFFFu;
                 hbuckets = 0ull;
+            }
+            if (kTies) {
+                // (hbuckets has one bit per slot in which the lane holds the maximum)
+                holder_mask = __ballot(hbuckets != 0ull);
+                multi_mask = __ballot(mixed);
             }
         }
         const int buf = it & 1;
@@ -547,11 +555,13 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
         cy = rec.y;
         cz = rec.z;
         if (kTies) {
-            // this wave's (exact, possibly cached) maximum equals the winner's distance: a tie unless it IS the winner alone.
+            // this wave's (exact, possibly cached) maximum equals the winner's distance, and one of its holders is not the
+            // winner's exact twin (the winner's own lane compares equal to itself): a tie that picks between coordinates.
             // Branch-free (a scalar branch here would put a VALU -> SALU round trip on every wave's critical path)
-            const bool mine = (int)((klo & 1023u) >> 6) == wave;
-            const bool other = !mine || wave_multi;
-            tied_v = min(tied_v, __builtin_amdgcn_readfirstlane((wbest == (int)(unsigned)(kfull >> 32) && other) ? it : 0x7fffffff));  // an SGPR
+            const unsigned long long differs = __ballot(xa != cx || ya != cy || za != cz);   // (stale in non-holders: masked)
+            const bool other = ((differs & holder_mask) | multi_mask) != 0ull;
+            const int wd = (int)(unsigned)(kfull >> 32);
+            tied_v = min(tied_v, __builtin_amdgcn_readfirstlane(((wbest == wd && other) || wd == 0) ? it : 0x7fffffff));  // an SGPR
         }
         const int kb2 = kb == 0 ? 2 : kb - 1;  // == (it + 2) % 3: last read in round it-1, next used in round it+2
         kb = kb == 2 ? 0 : kb + 1;
@@ -726,9 +736,6 @@ __device__ __forceinline__ unsigned rank16(int k) { return (bitrev_lg((unsigned)
 __device__ __forceinline__ int unrank16(unsigned r) { return (int)(bitrev_lg(r >> 6, 10) + ((r & 63u) << 10)); }
 
 constexpr int kBigThreads = 1024;
-#ifdef EPNET_BIG_DEBUG
-__device__ int g_dbg[4096];
-#endif
 
 __global__ __launch_bounds__(kBigThreads) void fps_bigscene_kernel(int n, int np, int m, const float *__restrict__ xyz,
                                                                   const float4 *__restrict__ sorted,
@@ -767,25 +774,14 @@ __global__ __launch_bounds__(kBigThreads) void fps_bigscene_kernel(int n, int np
     unsigned brank = 0xFFFFu;   // reference rank of the point holding it
     float bxx = 0.f, byy = 0.f, bzz = 0.f;
 
-    // original indices of this wave's 64 x 64 points, two per register (positions >= n are padding: the sort puts them last)
-    typedef int veck __attribute__((ext_vector_type(32)));
-    veck kk;
-#pragma unroll
-    for (int j = 0; j < 64; j += 2) {
-        const int p0 = (bid(j) << 6) + lane, p1 = (bid(j + 1) << 6) + lane;
-        const unsigned k0 = p0 < n ? (unsigned)__float_as_int(sorted[p0].w) : 0xFFFFu;
-        const unsigned k1 = p1 < n ? (unsigned)__float_as_int(sorted[p1].w) : 0xFFFFu;
-        kk[j >> 1] = (int)(k0 | (k1 << 16));
-    }
-    auto k_of = [&](int j) { return (int)(((unsigned)kk[j >> 1] >> ((j & 1) << 4)) & 0xFFFFu); };
-
     // The caller's running distances are indexed by ORIGINAL point number: a bucket's 64 values would be 64 cache lines.
     // The rounds keep them in SORTED order instead, in the sampling scratch at the tail of the scene index (one 256-byte
     // row per bucket, fetched beside the bucket's 1 KB row of the index); gathered on the way in, scattered back on the
-    // way out.
+    // way out. (The original index of a point rides in the .w of its index row: nothing per point is kept in registers --
+    // a 16-wave workgroup that holds few registers leaves the rest of the CU to the bandwidth-bound kernels beside it.)
     for (int j = 0; j < 64; ++j) {
         const int pos = (bid(j) << 6) + lane;
-        if (pos < n) tsort[pos] = temp[k_of(j)];
+        if (pos < n) tsort[pos] = temp[__float_as_int(sorted[pos].w)];
     }
 
     struct Row {
@@ -802,7 +798,7 @@ __global__ __launch_bounds__(kBigThreads) void fps_bigscene_kernel(int n, int np
     // (re)computes the summary of bucket j of this wave from its row; with `update`, first lowers its distances by the sample c
     auto finish = [&](int j, Row r, bool update, float cx, float cy, float cz) {
         const int pos = (bid(j) << 6) + lane;
-        const int k = k_of(j);
+        const int k = __float_as_int(r.p.w);   // original index (padding rows: -1, never `real`)
         const bool real = pos < n;
         int t = r.t;
         if (real && update) {
@@ -866,9 +862,6 @@ __global__ __launch_bounds__(kBigThreads) void fps_bigscene_kernel(int n, int np
             if (two) finish(j1, r1, true, cx, cy, cz);
         }
         // C. this wave's best bucket (ties by rank)
-#ifdef EPNET_BIG_NOCACHE
-        stale = true;
-#endif
         if (stale) {
             stale = false;
             wbest = wave_max_all(bm);
@@ -913,7 +906,7 @@ __global__ __launch_bounds__(kBigThreads) void fps_bigscene_kernel(int n, int np
     __builtin_amdgcn_s_setprio(0);
     for (int j = 0; j < 64; ++j) {
         const int pos = (bid(j) << 6) + lane;
-        if (pos < n) temp[k_of(j)] = tsort[pos];
+        if (pos < n) temp[__float_as_int(sorted[pos].w)] = tsort[pos];
     }
 }
 
@@ -1261,7 +1254,8 @@ extern "C" int epnet_sample_centres(int b, int n, int m, const float *xyz, const
 // furthest-point samples OF that sequence (the global maximiser over all points is itself one of the candidates; the running
 // distances are the same fp32 values), so idx = 0 .. m'-1 -- bit for bit what the reference's kernel computes on the centres,
 // whose tie-break only matters among equal maxima. prefix_in[b] (or NULL) = the number of leading rounds of the sampling that
-// produced xyz in which the maximum was unique; scenes with prefix_in[b] >= m take the identity, the others run the rounds.
+// produced xyz in which the maximum was unique up to exact twins; scenes with prefix_in[b] >= m take the identity, the others run
+// the rounds.
 // prefix_out[b] (or NULL) receives the same knowledge about THIS sampling's output (0 where the kernel cannot tell), looked
 // for during the first prefix_cap rounds only (<= 0: all rounds) -- the next level's sample count is all anybody will ask for.
 extern "C" int epnet_sample_centres_chain(int b, int n, int m, const float *xyz, const void *index, size_t index_bytes,

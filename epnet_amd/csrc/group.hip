@@ -462,7 +462,7 @@ __global__ __launch_bounds__(kGThreads) void group_linear_grad_w_kernel(int c, i
 // and written back out transposed, 256 contiguous bytes per channel row and wave. Extra traffic: the features once more
 // (c * n * 8 bytes per scene against c * p * 4 of output, p = npoints * nsample >> n).
 constexpr int kPmThreads = 256;
-constexpr int kPmTile = 128;  // positions per workgroup: 33 KB of LDS at c = 64, four workgroups per CU
+constexpr int kPmTile = 128;  // positions per workgroup: 32 KB of LDS at c = 64, four workgroups per CU
 
 __global__ __launch_bounds__(256) void transpose_cn_kernel(int c, int n, const float *__restrict__ src, float *__restrict__ dst) {
     __shared__ float tile[64][65];
@@ -477,14 +477,21 @@ __global__ __launch_bounds__(256) void transpose_cn_kernel(int c, int n, const f
         if (n0 + r < n && c0 + tx < c) dst[(size_t)(n0 + r) * c + c0 + tx] = tile[tx][r];
 }
 
-// points_t (b, n, c) point-major; out rows (b, c, p) with row stride ostride between scenes; c % 4 == 0, 16 <= c <= 128
+// points_t (b, n, c) point-major; out rows (b, c, p) with row stride ostride between scenes; c % 4 == 0, 16 <= c <= 128.
+// LDS tile [c][kPmTile], channel-major, with the 16-byte groups of a channel row swizzled by the channel
+// (position r of channel ch sits at r ^ (((ch >> 2) & 7) << 2)): the staging writes of a wave (4 rows x 16 lanes x 4 channels)
+// fall on 32 banks two at a time (free for ds_write_b32), and the read-back is one conflict-free ds_read_b128 per lane --
+// four consecutive positions of one channel, stored with ONE 16-byte streaming store (the 4-byte stores of the first
+// version were store-issue bound: 256 B per wave-instruction).
+__device__ __forceinline__ int pm_slot(int ch, int r) { return ch * kPmTile + (r ^ (((ch >> 2) & 7) << 2)); }
+
 __global__ __launch_bounds__(kPmThreads) void gather_rows_pm_kernel(int c, int n, int p, size_t ostride,
                                                                     const float *__restrict__ points_t,
                                                                     const int *__restrict__ idx, float *__restrict__ out) {
-    extern __shared__ float s_tile[];  // [kPmTile][c + 1]: the odd stride keeps the transposed reads conflict-free
+    extern __shared__ float s_tile[];  // [c][kPmTile]
     const int bs = blockIdx.y, q0 = blockIdx.x * kPmTile;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int cs = c + 1, lanes_per_row = c >> 2, rows_per_pass = kPmThreads / lanes_per_row;
+    const int lanes_per_row = c >> 2, rows_per_pass = kPmThreads / lanes_per_row;
     points_t += (size_t)bs * n * c;
     idx += (size_t)bs * p;
     out += (size_t)bs * ostride;
@@ -507,19 +514,30 @@ __global__ __launch_bounds__(kPmThreads) void gather_rows_pm_kernel(int c, int n
             for (int k = 0; k < kMaxPass; ++k) {
                 const int r = r0 + k * rows_per_pass;
                 if (r < cnt) {
-                    float *d = s_tile + r * cs + l_in * 4;
-                    d[0] = v[k].x; d[1] = v[k].y; d[2] = v[k].z; d[3] = v[k].w;
+                    const int ch = l_in * 4;   // four channels of one swizzle group: the same position offset for all four
+                    float *d = s_tile + pm_slot(ch, r);
+                    d[0] = v[k].x; d[kPmTile] = v[k].y; d[2 * kPmTile] = v[k].z; d[3 * kPmTile] = v[k].w;
                 }
             }
         }
     }
     __syncthreads();
-    for (int ch = wave; ch < c; ch += kPmThreads / 64) {
-        float *dst = out + (size_t)ch * p + q0;
+    const bool wide = cnt == kPmTile && (p & 3) == 0 && (((uintptr_t)out) & 15) == 0;   // (workgroup-uniform)
+    if (wide) {
+        // a wave-instruction covers two channel rows: lanes 0-31 the 128 positions of channel ch, lanes 32-63 those of ch + 1
+        const int half = lane >> 5, l = lane & 31;
+        for (int ch = wave * 2 + half; ch < c; ch += (kPmThreads / 64) * 2) {
+            const float4 v = *reinterpret_cast<const float4 *>(s_tile + pm_slot(ch, l * 4));
+            store_stream(out + (size_t)ch * p + q0 + l * 4, v.x, v.y, v.z, v.w);
+        }
+    } else {
+        for (int ch = wave; ch < c; ch += kPmThreads / 64) {
+            float *dst = out + (size_t)ch * p + q0;
 #pragma unroll
-        for (int k = 0; k < kPmTile / 64; ++k) {
-            const int r = k * 64 + lane;
-            if (r < cnt) __builtin_nontemporal_store(s_tile[r * cs + ch], dst + r);
+            for (int k = 0; k < kPmTile / 64; ++k) {
+                const int r = k * 64 + lane;
+                if (r < cnt) __builtin_nontemporal_store(s_tile[pm_slot(ch, r)], dst + r);
+            }
         }
     }
 }
@@ -546,7 +564,7 @@ static int launch_gather_rows_pm(int b, int c, int n, long long p, const float *
         int rc = check_launch("feature transpose");
         if (rc) return rc;
         hipLaunchKernelGGL(gather_rows_pm_kernel, dim3((unsigned)div_up64(p, kPmTile), nb), dim3(kPmThreads),
-                           (size_t)kPmTile * (c + 1) * sizeof(float), s, c, n, (int)p, ostride, dst, idx + (size_t)b0 * p,
+                           (size_t)kPmTile * c * sizeof(float), s, c, n, (int)p, ostride, dst, idx + (size_t)b0 * p,
                            out + (size_t)b0 * ostride);
         rc = check_launch(what);
         if (rc) return rc;

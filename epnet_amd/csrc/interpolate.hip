@@ -294,9 +294,12 @@ __global__ __launch_bounds__(kNnTileThreads) void three_nn_tile_kernel(int n, in
     // (float)1e40 = +inf and take a point only if d < best (interpolate_gpu.cu:30-48), so a distance of +inf (padding rows carry
     // 3e38 coordinates: their d overflows) or NaN (bits above +inf's) never enters -- with this start value the plain key order
     // says exactly that, and the distance bits need no validity mask at all.
-    // The keys are held and ordered AS DOUBLES: the high word is at most a float NaN's 0x7FFFFFFF, below the double exponent
-    // of all ones (0x7FF00000), so every key is a finite non-negative double (|x| is applied to the candidate: a negative float
-    // NaN becomes a positive one), and for those the order of the values is the order of the bit patterns. A sorted insertion
+    // The keys are held and ordered AS DOUBLES. A finite distance or +inf has a high word <= 0x7F800000, below the double exponent
+    // of all ones (0x7FF00000): a finite non-negative double, and for those the order of the values is the order of the bit
+    // patterns. A float NaN does NOT stay below it (payloads run up to 0x7FFFFFFF / 0xFFFFFFFF, and NaN inputs propagate their
+    // payload): as a double NaN it would make v_min_f64 / v_max_f64 return the other operand and duplicate an entry. So the
+    // candidate's distance bits are clamped to +inf's first (one v_min_u32: a NaN of either sign is above 0x7F800000 as an
+    // unsigned word); the key (+inf, k) then sorts behind the empty slot (+inf, INT_MIN) and never enters. A sorted insertion
     // is then five v_min_f64 / v_max_f64 (full rate, branch-free, exact; a key with d = 0 is a denormal double: the f64
     // denormal mode of a HIP kernel is IEEE) instead of three 64-bit compares and ten selects.
     constexpr unsigned kInf = 0x7F800000u;
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(kNnTileThreads) void three_nn_tile_kernel(int n, in
     typedef float f2 __attribute__((ext_vector_type(2)));
     const f2 ux2 = {u.x, u.x}, uy2 = {u.y, u.y}, uz2 = {u.z, u.z};
     auto insert = [&](unsigned db, int k) {
-        const double e = __hiloint2double((int)db, (int)((unsigned)k ^ 0x80000000u));
+        const double e = __hiloint2double((int)min(db, kInf), (int)((unsigned)k ^ 0x80000000u));
         double t0, r0, t1, r1, t2;  // (inline asm: through fmin / fmax the compiler adds a canonicalising v_max_f64 x,x per operand)
         asm("v_min_f64 %0, |%1|, %2" : "=v"(t0) : "v"(e), "v"(e0));
         asm("v_max_f64 %0, |%1|, %2" : "=v"(r0) : "v"(e), "v"(e0));

@@ -262,6 +262,30 @@ def ball_query_multi_wrapper(b, n, m, radii, nsamples, new_xyz, xyz, index, idxs
     return 1
 
 
+@writes("idxs")
+def ball_query_ordered_wrapper(b, n, m, radii, nsamples, new_xyz, xyz, index, centre_index, idxs):
+    """ball_query_multi_wrapper with the centres served in their own spatial order: centre_index = the scene index of the cloud new_xyz
+    (the next SA level's index of its input points); None falls back to ball_query_multi_wrapper's path. Same results."""
+    import ctypes
+    pn, pxyz = dev_ptr(new_xyz, "new_xyz", _F), dev_ptr(xyz, "xyz", _F)
+    need(new_xyz, b * m * 3, "new_xyz"); need(xyz, b * n * 3, "xyz")
+    k = len(radii)
+    assert len(nsamples) == k and len(idxs) == k
+    ptrs = []
+    for ns, t in zip(nsamples, idxs):
+        ptrs.append(dev_ptr(t, "idx", _I))
+        need(t, b * m * ns, "idx")
+    px, nb = _index_args(index, xyz)
+    pc, nc = _index_args(centre_index, new_xyz)
+    c_r = (ctypes.c_float * k)(*[float(r) for r in radii])
+    c_n = (ctypes.c_int * k)(*[int(x) for x in nsamples])
+    c_p = (ctypes.c_void_p * k)(*ptrs)
+    with on_device_of(xyz) as s:
+        _lib.check(_lib.lib().epnet_ball_query_ordered(b, n, m, k, ctypes.cast(c_r, ctypes.c_void_p), ctypes.cast(c_n, ctypes.c_void_p),
+                                                     pn, pxyz, px, nb, pc, nc, ctypes.cast(c_p, ctypes.c_void_p), s), "ball_query")
+    return 1
+
+
 @writes("dist2", "idx")
 def three_nn_indexed_wrapper(b, n, m, unknown, known, unknown_index, known_index, dist2, idx):
     """three_nn_wrapper over scene indices of `known` and (optionally) of `unknown` (same results)"""

@@ -131,6 +131,7 @@ class SAStack:
         self.tail_scales = int(os.environ.get("EPNET_SA_TAIL_SCALES", "0"))
         self.multi_query = bool(int(os.environ.get("EPNET_SA_MULTI_QUERY", "1")))  # both scales of a level in one launch
         self.multi_group = bool(int(os.environ.get("EPNET_SA_MULTI_GROUP", "1")))  # both groupings of a level in one call
+        self.ordered_query = bool(int(os.environ.get("EPNET_SA_ORDERED_QUERY", "1")))   # centres served in their spatial order (epnet_ball_query_ordered)
         self.side = None
         self.npoints, self.radii, self.nsamples, self.feat_channels = npoints, radii, nsamples, feat_channels
         self.with_fp, self.fp = with_fp, fp
@@ -151,7 +152,10 @@ class SAStack:
                 # what G reads from S, one set per pipeline parity
                 "sets": [{"new_xyz": torch.empty((batch, m, 3), dtype=f32, device=dev),
                           "index": (torch.empty((index_bytes,), dtype=torch.uint8, device=dev) if index_bytes else None),
-                          "prefix": torch.zeros((batch,), dtype=i32, device=dev)}   # tie-free leading rounds of this level's sampling
+                          "prefix": torch.zeros((batch,), dtype=i32, device=dev),   # tie-free leading rounds of this level's sampling
+                          # the last level's centres have no next level to index them: their own index for the ordered ball query
+                          "centre_index": (torch.empty((ext.scene_index_bytes(batch, m),), dtype=torch.uint8, device=dev)
+                                           if (shared_index and lvl + 1 == len(npoints) and ext.scene_index_bytes(batch, m)) else None)}
                          for _ in range(2 if pipelined else 1)],
                 "features": (torch.randn((batch, c, cur), generator=g, dtype=f32).to(dev) if c else None),
                 "scales": [],
@@ -287,13 +291,29 @@ class SAStack:
     def _query_level(self, L, cur_xyz, parity):
         """the ball queries of all scales of the level: one launch over the shared index"""
         P = L["sets"][parity]
-        if P["index"] is not None and self.multi_query:
+        centre_index = self._centre_index(L, parity) if (self.ordered_query and P["index"] is not None and len(L["scales"]) <= 2) else None
+        if centre_index is not None:   # the centres in the order of their own scene index
+            ext.ball_query_ordered_wrapper(self.batch, L["n"], L["m"], [S["radius"] for S in L["scales"]],
+                                         [S["ns"] for S in L["scales"]], P["new_xyz"], cur_xyz, P["index"], centre_index,
+                                         [self._idx(S, parity) for S in L["scales"]])
+        elif P["index"] is not None and self.multi_query:
             ext.ball_query_multi_wrapper(self.batch, L["n"], L["m"], [S["radius"] for S in L["scales"]],
                                          [S["ns"] for S in L["scales"]], P["new_xyz"], cur_xyz, P["index"],
                                          [self._idx(S, parity) for S in L["scales"]])
         else:
             for S in L["scales"]:
                 self._query_scale(L, S, cur_xyz, parity)
+
+    def _centre_index(self, L, parity):
+        """the scene index of this level's centres: the next level's index of its input (built by the sampling chain before anybody
+        queries), or -- last level with >= 1024 centres -- one built here, just before the query that reads it"""
+        lvl = self.levels.index(L)
+        if lvl + 1 < len(self.levels):
+            return self.levels[lvl + 1]["sets"][parity]["index"] if self.shared_index else None
+        own = L["sets"][parity].get("centre_index")
+        if own is not None:
+            ext.scene_index_build_wrapper(self.batch, L["m"], L["sets"][parity]["new_xyz"], own)
+        return own
 
     def _group_scales(self, L, cur_xyz, parity):
         """the groupings of all scales of the level: one call (feature rows staged once for both scales)"""
@@ -319,8 +339,15 @@ class SAStack:
         main = torch.cuda.current_stream(xyz.device)
         side = self._side_stream(xyz.device) if self.overlap else None
         cur_xyz = xyz
-        for L in self.levels:
-            new_xyz = self._sample_level(L, cur_xyz, 0)
+        built = False
+        for lvl, L in enumerate(self.levels):
+            new_xyz = self._sample_level(L, cur_xyz, 0, index_built=built)
+            built = False
+            nxt = self.levels[lvl + 1] if lvl + 1 < len(self.levels) else None
+            if self.ordered_query and nxt is not None and nxt["sets"][0]["index"] is not None:
+                # the ordered ball query of this level walks the index of its centres = the next level's index of its input
+                ext.scene_index_build_wrapper(self.batch, L["m"], new_xyz, nxt["sets"][0]["index"])
+                built = True
             if side is not None:
                 side.wait_stream(main)
                 with torch.cuda.stream(side):

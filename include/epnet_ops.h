@@ -222,7 +222,10 @@ int epnet_sample_centres(int b, int n, int m, const float *xyz, const void *inde
  * sampling is nested: while every round's maximum is unique, the first m samples of a furthest-point sequence ARE the
  * furthest-point samples of that sequence -- idx = 0 .. m-1, bit for bit what sampling_gpu.cu:94-209 computes on the centres
  * (its tie-break matters among equal maxima only). prefix_in (b ints or NULL): leading rounds of the sampling that produced xyz
- * in which the maximum was unique (= the prefix_out of that call); scenes with prefix_in[b] >= m take the identity, the others
+ * in which the maximum was unique up to exact twins -- points with identical coordinates, as the reference's loader creates when
+ * it pads a short scene (kitti_rcnn_dataset.py:338-342): the unpicked twin is at distance 0 from then on and cannot be sampled
+ * while the maximum is positive, so the sequence of sampled COORDINATES does not depend on the tie-break (= the prefix_out of
+ * that call); scenes with prefix_in[b] >= m take the identity, the others
  * run the rounds. prefix_out (b ints or NULL): the same knowledge about this call's output (at least that many rounds), 0 where
  * the kernel cannot tell; ties are looked for during the first prefix_cap rounds only (<= 0: all) -- pass the next level's m.
  * new_xyz may be NULL here (indices only: the centres then come out of epnet_scene_index_build_gathered of the next level). */
@@ -243,6 +246,15 @@ int epnet_ball_query_indexed(int b, int n, int m, float radius, int nsample, con
 int epnet_ball_query_indexed_multi(int b, int n, int m, int nscales, const float *radii, const int *nsamples,
                                    const float *new_xyz, const float *xyz, const void *index, size_t index_bytes,
                                    int *const *idx, epnet_stream_t stream);
+/* The same queries with the centres served in THEIR spatial order (ball_query_gpu.cu:9-45 gives thread i centre i; the centres of an
+ * SA level come in furthest-point order, which scatters consecutive centres over the whole scene). centre_index = the scene index
+ * (epnet_scene_index_build / _build_gathered) of the cloud new_xyz (b, m, 3), in that order -- the next SA level samples the
+ * centres, so the stack has it anyway: wave w serves the w-th centre of that order, its neighbours walk the same point buckets,
+ * which are then cache hits. nscales 1 or 2 (otherwise, or with centre_index == NULL, or for m < 1024:
+ * epnet_ball_query_indexed_multi). Results identical to epnet_ball_query per scale. */
+int epnet_ball_query_ordered(int b, int n, int m, int nscales, const float *radii, const int *nsamples, const float *new_xyz,
+                             const float *xyz, const void *index, size_t index_bytes, const void *centre_index,
+                             size_t centre_index_bytes, int *const *idx, epnet_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------
  * iou3d (lib/utils/iou3d/src/iou3d.cpp:174-179); boxes are (N,5) [x1,y1,x2,y2,ry] f32

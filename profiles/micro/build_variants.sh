@@ -1,6 +1,6 @@
 # builds variants of libepnet_hip.so with different -D flags into scratch/libs/
-set -e
-cd /root/repo/epnet_amd/csrc
+set -eu
+cd "$(dirname "$0")/../../epnet_amd/csrc"
 mkdir -p ../../scratch/libs
 F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -mllvm -amdgpu-atomic-optimizer-strategy=None -I../../include -I."
 i=0

@@ -595,13 +595,18 @@ def test_three_nn_non_finite_coordinates(oracle, tile, monkeypatch):
     unknown = rand_cloud(b, n, seed=21, kind="kitti")
     known = rand_cloud(b, m, seed=22, kind="kitti")
     neg_nan = np.frombuffer(np.uint32(0xFFC00000).tobytes(), dtype=np.float32)[0]
-    bad = [np.float32(np.nan), neg_nan, np.float32(np.inf), np.float32(-np.inf)]
+    # NaN payloads propagate through the subtraction and the squares: the distance of such a point carries them, and bits from
+    # 0x7FF00000 up are a NaN as the high word of a double as well (the canonical 0x7FC00000 alone cannot show that)
+    bad_bits = [0x7FC00000, 0xFFC00000, 0x7F800000, 0xFF800000, 0x7FFFFFFF, 0xFFFFFFFF, 0x7FF00001, 0xFFF80000]
     rng = np.random.default_rng(5)
-    for arr, count in ((known, 40), (unknown, 60)):
+    for arr, count in ((known, 64), (unknown, 96)):
+        bits = arr.view(np.uint32)          # (written as bit patterns: no float move may quieten or canonicalise them)
         for k in range(count):
-            arr[rng.integers(0, b), rng.integers(0, arr.shape[1]), rng.integers(0, 3)] = bad[k % 4]
+            bits[rng.integers(0, b), rng.integers(0, arr.shape[1]), rng.integers(0, 3)] = bad_bits[k % len(bad_bits)]
     known[1, 7] = [neg_nan, neg_nan, neg_nan]
+    known.view(np.uint32)[1, 9] = [0x7FFFFFFF, 0xFFFFFFFF, 0x7FFFFFFF]
     unknown[0, 11] = [np.float32(np.inf), np.float32(-np.inf), neg_nan]
+    unknown.view(np.uint32)[0, 13] = [0xFFFFFFFF, 0x7FFFFFFF, 0x7FF00001]
     d_u, d_k = dev(unknown), dev(known)
     o_d2, o_i = oracle.three_nn(unknown, known)
     assert np.isinf(o_d2).any() and np.isfinite(o_d2).any()
@@ -1187,6 +1192,28 @@ def test_group_concat_long_rows_through_point_major_scratch(oracle, b, c, n, m, 
     np.testing.assert_array_equal(host(only), want_feat)
 
 
+def _plant_near_twin_tie(oracle, cloud, slot, seq, around, m):
+    """writes to cloud[slot] coordinates a few ulps from a point picked in some round R >= `around` such that the two tie (not as
+    exact twins) in round R of the sampling and nothing ties before -- found by trying nudges against the brute-force tie finder.
+    Returns R."""
+    import itertools
+    import sys
+    sys.path.insert(0, __import__("os").path.dirname(__file__))
+    from test_oracle_second_derivation import first_tie_round
+    bs = oracle.opt_n_threads(cloud.shape[0])
+    for at_round in range(around, around + 40):
+        for axis, k in itertools.product((1, 0, 2), (1, -1, 2, -2, 3, -3)):
+            q = cloud[seq[at_round]].copy()
+            for _ in range(abs(k)):
+                q[axis] = np.nextafter(q[axis], np.float32(np.inf if k > 0 else -np.inf))
+            trial = cloud.copy()
+            trial[slot] = q
+            if first_tie_round(trial, m, bs, twins_are_ties=False)[0] == at_round:
+                cloud[slot] = q
+                return at_round
+    raise AssertionError("no near twin ties around round %d" % around)
+
+
 def _lattice_cloud(n, seed):
     rng = np.random.default_rng(seed)
     base = rng.integers(-8, 9, size=(max(4, (n * 3) // 4), 3)).astype(np.float32) * np.float32(0.5)
@@ -1197,29 +1224,40 @@ def _lattice_cloud(n, seed):
 @pytest.mark.parametrize("kind,n,pyramid", [("kitti", 16384, (4096, 1024, 256, 64)), ("dup", 16384, (4096, 1024, 256, 64)),
                                             ("ubox", 4096, (1024, 256, 64)), ("lattice", 4096, (1024, 256, 64)),
                                             ("lattice", 16384, (4096, 1024, 256, 64)), ("kitti", 3000, (700, 300, 100)),
-                                            ("kitti_twin", 16384, (4096, 1024, 256, 64))])
+                                            ("kitti_twin", 16384, (4096, 1024, 256, 64)), ("dup_shuffled", 16384, (4096, 1024, 256, 64)),
+                                            ("few_distinct", 4096, (1024, 256, 64)), ("kitti_q", 16384, (4096, 1024, 256, 64))])
 def test_sampling_chain_matches_oracle_and_reports_exact_tie_rounds(oracle, kind, n, pyramid):
     """epnet_sample_centres_chain over a whole pyramid: every level's indices and centres equal the oracle's (which runs the
-    reference's rounds on every level), whether a level took the identity (tie-free prefix known) or ran its rounds (ties: the
-    lattice cloud, duplicated rows). The first level's reported tie-free round count equals the count found by brute force"""
+    reference's rounds on every level), whether a level took the identity (tie-free prefix known) or ran its rounds (ties between
+    DIFFERENT coordinates: the lattice cloud). Exact twins (duplicated rows, the reference loader's padding) tie harmlessly and do
+    not end the prefix. The first level's reported round count equals the count found by brute force"""
     import sys
     sys.path.insert(0, __import__("os").path.dirname(__file__))
     from test_oracle_second_derivation import first_tie_round
     from epnet_amd import pointnet2_cuda as ext
     b = 3
     if kind == "kitti_twin":
-        # a tie in the MIDDLE of the first level's rounds: the point picked in round 300 + 200 s gets an exact twin (written over a
-        # point that is never picked), so the deeper levels know a prefix of that length and resume their rounds from there
+        # an exact twin of the point picked in round 100 + 50 s (harmless: the prefix runs through it) AND a tie between DIFFERENT
+        # coordinates in the MIDDLE of the first level's rounds: a never-picked point is moved next to the point picked in round
+        # ~300 + 200 s, a few ulps off, where its fp32 running distance at that round is bit-identical -- so the deeper levels know a
+        # prefix of about that length and resume their rounds from there
         clouds = np.stack([rand_cloud(1, n, seed=60 + s, kind="kitti")[0] for s in range(b)])
         for s_ in range(b):
             seq = oracle.furthest_point_sampling(clouds[s_:s_ + 1], pyramid[0])[0]
-            never = np.setdiff1d(np.arange(n), seq)[7]
-            clouds[s_, never] = clouds[s_, seq[300 + 200 * s_]]
+            never = np.setdiff1d(np.arange(n), seq)
+            clouds[s_, never[3]] = clouds[s_, seq[100 + 50 * s_]]
+            tied_at = _plant_near_twin_tie(oracle, clouds[s_], never[7], seq, 300 + 200 * s_, pyramid[0])
+            assert 300 + 200 * s_ <= tied_at < 340 + 200 * s_
+    elif kind == "dup_shuffled":   # what the loader does: pad by re-drawing rows, then shuffle (kitti_rcnn_dataset.py:338-342)
+        clouds = np.stack([rand_cloud(1, n, seed=60 + s, kind="dup")[0][np.random.default_rng(s).permutation(n)] for s in range(b)])
+    elif kind == "few_distinct":   # fewer distinct points than level-2 samples: the maximum reaches zero, the identity must end there
+        clouds = np.stack([rand_cloud(1, nd, seed=60 + s, kind="kitti")[0][np.random.default_rng(s).integers(0, nd, size=n)]
+                           for s, nd in enumerate((150, 300, 500))])
     else:
         clouds = np.stack([_lattice_cloud(n, 40 + s) if kind == "lattice" else rand_cloud(1, n, seed=60 + s, kind=kind)[0] for s in range(b)])
     cur_h, cur = clouds, dev(clouds)
     prefix_in = None
-    took_identity = []
+    took_identity, level1_ties = [], []
     for lvl, m in enumerate(pyramid):
         nn = cur.shape[1]
         index = ext.scene_index(cur)
@@ -1234,14 +1272,23 @@ def test_sampling_chain_matches_oracle_and_reports_exact_tie_rounds(oracle, kind
         po = host(prefix_out)
         if lvl == 0 and 1024 < nn <= 16384:   # the pruned kernels report ties exactly
             for s_ in range(b):
-                tie, _ = first_tie_round(cur_h[s_], m, oracle.opt_n_threads(nn))
+                tie, _ = first_tie_round(cur_h[s_], m, oracle.opt_n_threads(nn), twins_are_ties=False)
                 assert po[s_] == tie, (s_, po[s_], tie)
+                level1_ties.append(tie)
+                if kind in ("dup", "dup_shuffled"):   # the twins do tie, early; the prefix runs through them
+                    assert first_tie_round(cur_h[s_], m, oracle.opt_n_threads(nn))[0] < min(tie, pyramid[1])
         if prefix_in is not None:
             took_identity.append((host(prefix_in) >= m).tolist())
         assert (po >= 0).all() and (po <= max(m, int(host(prefix_in).max()) if prefix_in is not None else m)).all()
         cur_h, cur, prefix_in = want_c, centres, prefix_out
     if kind in ("kitti", "ubox") and n > 1024:
-        assert all(all(t) for t in took_identity)            # no ties: every deeper level is the identity
+        assert all(all(t) for t in took_identity)            # no ties between different coordinates: every deeper level is the identity
+    if kind in ("dup", "dup_shuffled"):
+        # level 2 is the identity exactly where no tie between DIFFERENT coordinates fell into its rounds (fp32 distances of
+        # 16384 points do collide now and then: about one scene in 40); the twins alone never end it
+        assert took_identity[0] == [t >= pyramid[1] for t in level1_ties] and any(took_identity[0])
+    if kind == "few_distinct":
+        assert took_identity[0] == [False, True, True]        # 150 distinct points < 256 samples of level 2; 300 and 500 are not
     if kind == "lattice":
         assert not any(any(t) for t in took_identity)        # ties from the first rounds on: every level ran its rounds
     if kind == "kitti_twin":

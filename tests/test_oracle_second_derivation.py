@@ -80,9 +80,12 @@ def test_fps_rank_rule_on_continuous_cloud(oracle):
     np.testing.assert_array_equal(oracle.furthest_point_sampling(xyz[None], 700)[0], want)
 
 
-def first_tie_round(xyz, m, bs):
+def first_tie_round(xyz, m, bs, twins_are_ties=True):
     """the first round of the furthest point sampling of ONE scene whose maximum running distance is held by several points
-    (m if there is none): numpy, the rank rule of fps_rank_rule"""
+    (m if there is none): numpy, the rank rule of fps_rank_rule.
+    twins_are_ties=False: holders with IDENTICAL coordinates do not count as a tie while the maximum is positive (whichever
+    of them the tie-break picks, the others drop to distance 0 in the next round and can never be sampled while some point
+    is further than 0 from the samples: the sequence of sampled COORDINATES does not depend on the tie-break)."""
     n = xyz.shape[0]
     k = np.arange(n)
     rank = bit_reverse(k % bs, int(math.log2(bs))).astype(np.int64) * (n // bs + 2) + k // bs
@@ -92,10 +95,13 @@ def first_tie_round(xyz, m, bs):
     for it in range(1, m):
         dx, dy, dz = x - x[o], y - y[o], z - z[o]
         temp = np.minimum((dx * dx + dy * dy) + dz * dz, temp)
-        cand = np.flatnonzero(temp == temp.max())
+        top = temp.max()
+        cand = np.flatnonzero(temp == top)
         if cand.size > 1:
-            return it, np.array(picks, np.int32)
-        o = int(cand[0])
+            harmless = (not twins_are_ties) and top > 0 and len(np.unique(xyz[cand].view(np.uint32), axis=0)) == 1
+            if not harmless:
+                return it, np.array(picks, np.int32)
+        o = int(cand[np.argmin(rank[cand])])
         picks.append(o)
     return m, np.array(picks, np.int32)
 
@@ -117,6 +123,40 @@ def test_fps_is_nested_while_the_maxima_are_unique(oracle, kind, n, m, m2):
         assert tie == m            # continuous coordinates: no exact ties, the whole second level is the identity
     if kind == "lattice":
         assert tie < m2            # the lattice ties early: the case the chain must NOT shortcut
+
+
+@pytest.mark.parametrize("kind,n,m,m2", [("dup", 4096, 1024, 256), ("dup", 16384, 4096, 1024), ("dup_shuffled", 8192, 2048, 700),
+                                         ("lattice", 4096, 1024, 256), ("few_distinct", 2048, 512, 450)])
+def test_exact_twins_do_not_end_the_nesting(oracle, kind, n, m, m2):
+    """The reference's loader pads short scenes by re-drawing rows (kitti_rcnn_dataset.py:338-342): exact twins, which tie at the
+    round one of them is picked. Such a tie is harmless for the next level -- the unpicked twin never becomes a sample while
+    the maximum is positive -- so the nesting holds up to the first round whose maximum is held by DIFFERENT coordinates (or
+    is zero). Checked against the oracle's own rounds on the centres."""
+    from epnet_amd import synth
+    rng = np.random.default_rng(5)
+    if kind == "lattice":
+        xyz = clouds_with_duplicates(n, seed=3)
+    elif kind == "few_distinct":      # more samples than distinct points: the maximum reaches zero inside the first sampling
+        xyz = synth.kitti_like_cloud(400, 3).numpy()[rng.integers(0, 400, size=n)]
+    else:
+        xyz = synth.dup_cloud(n, 11, unique=(n * 3) // 4).numpy()
+        if kind == "dup_shuffled":
+            xyz = xyz[rng.permutation(n)]
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    bs = oracle.opt_n_threads(n)
+    strict, _ = first_tie_round(xyz, m, bs)
+    relaxed, picks = first_tie_round(xyz, m, bs, twins_are_ties=False)
+    idx = oracle.furthest_point_sampling(xyz[None], m)[0]
+    np.testing.assert_array_equal(idx[:len(picks)], picks)      # (the rank rule picks what the oracle picks, through the twin rounds too)
+    assert relaxed >= strict
+    centres = xyz[idx]
+    idx2 = oracle.furthest_point_sampling(centres[None], m2)[0]
+    upto = min(relaxed, m2)
+    np.testing.assert_array_equal(idx2[:upto], np.arange(upto))
+    if kind.startswith("dup"):
+        assert strict < m2 <= relaxed    # the twins tie early, yet the whole second level is the identity
+    if kind == "few_distinct":
+        assert relaxed <= 400 and not np.array_equal(idx2, np.arange(m2))    # zero maximum: the identity ends, and must be seen to
 
 
 def _tie_scene(n, at_unit_distance):
