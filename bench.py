@@ -52,6 +52,11 @@ def parse():
     ap.add_argument("--pipelined", type=int, default=int(os.environ.get("EPNET_BENCH_PIPELINED", "1")),
                     help="1: software-pipelined steps -- the (latency-bound) sampling chain of step k runs beside the "
                          "(bandwidth-bound) ball query + grouping of step k-1, double-buffered; 0: every step alone")
+    ap.add_argument("--stages", type=int, default=int(os.environ.get("EPNET_BENCH_STAGES", "2")), choices=[2, 3],
+                    help="software pipeline depth: 2 = sampling chain of step k beside grouping of step k-1; 3 = level-1 sampling of "
+                         "step k beside the rest of the sampling chain + ball queries of step k-1 beside the grouping of step k-2 (measured "
+                         "slower: 3.47 against 3.24 ms -- the short kernels of the middle stage need 126 - 129 registers per lane and find no "
+                         "place on a CU while the level-1 sampling holds 400 of its 512: profiles/r03_timeline_three_stages.txt)")
     ap.add_argument("--unfused", action="store_true", help="grouping as two group_points calls instead of group_concat")
     ap.add_argument("--no-shared-index", action="store_true", help="every op sorts the scene for itself")
     ap.add_argument("--fused-sampling", action="store_true", help="(default; kept for old command lines)")
@@ -151,16 +156,18 @@ def cpu_baseline_multicore(kind, n_points, procs, cfg, per_proc=2):
             "sample": "%d %s scenes over %d worker processes, %.1f s wall" % (len(seeds), kind, procs, wall)}
 
 
-def verify_scene(stack, xyz, scene, prev_xyz=None):
+def verify_scene(stack, xyz, scene, prev_xyz=None, prev2_xyz=None):
     """One scene of the buffers the timed steps left behind, checked against the CPU oracle DIRECTLY (not against another
     HIP path): every level's FPS indices and centres, both ball-query index tensors, both grouped tensors
     [xyz - centre ; features] (and, with the FP ops in the step, three_nn / three_interpolate). Integer outputs and copies
     must be identical; the interpolation is held to 1e-5. Returns the list of mismatching outputs (empty = verified).
 
-    A software-pipelined stack holds TWO batches after a step (SAStack.owners()): `xyz` is the batch the last step sampled
-    (stage S: fps_idx, its parity's centres / stage-S ball queries / FP searches), `prev_xyz` the batch it grouped (stage G:
-    the other parity's sets, the stage-G ball queries, every grouped tensor, the interpolation outputs) -- the batch of the
-    step before. prev_xyz=None: one batch replayed into both (or an unpipelined stack).
+    A software-pipelined stack holds several batches after a step (SAStack.owners() / owners3()): `xyz` is the batch the last step
+    sampled, `prev_xyz` the batch of the step before, `prev2_xyz` (three stages) the one before that; None: the same batch again.
+      two stages    stage S buffers (fps_idx, the sampling parity's sets / stage-S ball queries / FP searches) <-> xyz;
+                    stage G buffers (the other parity's sets, stage-G ball queries, grouped tensors, interpolation) <-> prev_xyz
+      three stages  slot S1: level-1 fps_idx <-> xyz (nothing else of that slot is current); slot S2: everything the sampling
+                    chain writes <-> prev_xyz; slot G: the same and every stage-G output <-> prev2_xyz (a complete batch)
     The oracle is the checker here, outside every timed region (oracle/oracle.py header)."""
     import numpy as np
     from oracle import oracle
@@ -192,25 +199,58 @@ def verify_scene(stack, xyz, scene, prev_xyz=None):
             fp.append((d2, nn_idx))
         return per_level, fp
 
-    s_par, g_par = stack.owners() if hasattr(stack, "owners") else (0, 0)
-    want_s = expected(xyz)
-    want_g = want_s if (prev_xyz is None or prev_xyz is xyz) else expected(prev_xyz)
+    cache = []
 
-    def owner(parity):   # the expectation a per-parity buffer is held to
-        return want_s if parity == s_par else want_g
+    def want_of(cloud):
+        for c, w in cache:
+            if c is cloud:
+                return w
+        cache.append((cloud, expected(cloud)))
+        return cache[-1][1]
+
+    prev_xyz = xyz if prev_xyz is None else prev_xyz
+    prev2_xyz = prev_xyz if prev2_xyz is None else prev2_xyz
+    stages = getattr(stack, "stages", 2 if getattr(stack, "pipelined", False) else 1)
+    # slot -> (expectation, "all" | "level-1 sampling only"); the batch stage G worked on
+    if stages == 3:
+        s1, s2, g = stack.owners3()
+        by_slot = {s1: (want_of(xyz), "l1"), s2: (want_of(prev_xyz), "all"), g: (want_of(prev2_xyz), "all")}
+        want_g = want_of(prev2_xyz)
+    elif stages == 2:
+        s_par, g_par = stack.owners()
+        by_slot = {s_par: (want_of(xyz), "all"), g_par: (want_of(prev_xyz), "all")}
+        want_g = want_of(prev_xyz)
+    else:
+        by_slot = {0: (want_of(xyz), "all")}
+        want_g = want_of(xyz)
 
     for lvl, L in enumerate(stack.levels):
         tag = "level%d." % (lvl + 1)
-        same(tag + "fps_idx", L["fps_idx"][scene:scene + 1], want_s[0][lvl]["fps"])       # written by stage S
+        fps_sets = L.get("fps_idx_sets") or [L["fps_idx"]]
+        if all(t is fps_sets[0] for t in fps_sets):      # one tensor: the sampling chain of the last step's batch wrote it
+            same(tag + "fps_idx", fps_sets[0][scene:scene + 1], want_of(xyz)[0][lvl]["fps"])
+        else:
+            for k, t in enumerate(fps_sets):
+                want, scope = by_slot[k]
+                if scope == "all" or lvl == 0:
+                    same(tag + "fps_idx[set %d]" % k, t[scene:scene + 1], want[0][lvl]["fps"])
         for k, P in enumerate(L["sets"]):
-            same(tag + "new_xyz[set %d]" % k, P["new_xyz"][scene:scene + 1], owner(k)[0][lvl]["new_xyz"])
+            want, scope = by_slot[k]
+            if scope == "all":
+                same(tag + "new_xyz[set %d]" % k, P["new_xyz"][scene:scene + 1], want[0][lvl]["new_xyz"])
         feats = None if L["features"] is None else L["features"][scene:scene + 1].cpu().numpy()
         G = want_g[0][lvl]
         for j, S in enumerate(L["scales"]):
             stag = tag + "r%g." % S["radius"]
             idx_sets = S.get("idx_sets", [S["idx"]])
-            for k, idx_set in enumerate(idx_sets):   # one per pipeline parity when the queries run in stage S, else stage G's own
-                want_bq = owner(k)[0][lvl]["bq"][j] if len(idx_sets) > 1 else G["bq"][j]
+            for k, idx_set in enumerate(idx_sets):   # one per ring slot when the queries run in stage S, else stage G's own
+                if len(idx_sets) > 1:
+                    want, scope = by_slot[k]
+                    if scope != "all":
+                        continue
+                    want_bq = want[0][lvl]["bq"][j]
+                else:
+                    want_bq = G["bq"][j]
                 same(stag + "ball_idx[set %d]" % k, idx_set[scene:scene + 1], want_bq)
             bq = G["bq"][j]
             want_xyz = oracle.group_points(G["cur_t"], bq) - G["new_xyz"].transpose(0, 2, 1)[:, :, :, None]   # pointnet2_utils.py:250-251
@@ -224,8 +264,11 @@ def verify_scene(stack, xyz, scene, prev_xyz=None):
                     same(stag + "grouped_feat", S["grouped_feat"][scene:scene + 1], want_feat)
     for k, F in enumerate(stack.fp_bufs if stack.with_fp else []):
         tag = "fp%d." % (len(stack.levels) - k)
-        for q, P in enumerate(F["sets"]):           # the searches run in stage S (one set per parity)
-            d2, nn_idx = owner(q)[1][k] if len(F["sets"]) > 1 else want_s[1][k]
+        for q, P in enumerate(F["sets"]):           # the searches run in stage S (one set per ring slot)
+            want, scope = by_slot[q] if len(F["sets"]) > 1 else (want_of(xyz), "all")
+            if scope != "all":
+                continue
+            d2, nn_idx = want[1][k]
             same(tag + "three_nn.idx[set %d]" % q, P["idx"][scene:scene + 1], nn_idx)
             same(tag + "three_nn.dist2[set %d]" % q, P["dist2"][scene:scene + 1], d2)
         d2, nn_idx = want_g[1][k]                   # the interpolation runs in stage G
@@ -417,27 +460,28 @@ def main():
         kind = args.kind if kind is None else kind
         points = args.points if cfg is args.cfg else cfg["n"]
         ids = scene_shard.scene_ids(batch * world, rank, world)           # round-robin shard of the global batch
+        stages = args.stages if pipelined else 1
         batches = [torch.stack([synth.cloud(kind, points, scene_shard.scene_seed(1 + which, i)) for i in ids]).to(dev)
-                   for which in range(2)]                                  # inputs resident in HBM
+                   for which in range(3 if stages == 3 else 2)]            # inputs resident in HBM
         stack = sa_stack.SAStack(batch, n=points, device=dev, with_fp=with_fp, seed=rank,
                                  npoints=cfg["npoints"], radii=cfg["radii"], nsamples=cfg["nsamples"],
                                  feat_channels=cfg["feat_channels"],
                                  overlap=not args.no_overlap, fused=not args.unfused,
                                  shared_index=not args.no_shared_index, pipelined=pipelined,
-                                 fused_sampling=not args.module_sampling)
+                                 fused_sampling=not args.module_sampling, stages=stages)
         count = [0]
         if args.no_graph:
             def step():
-                stack.step(batches[count[0] & 1])
+                stack.step(batches[count[0] % len(batches)])
                 count[0] += 1
         elif pipelined:
-            stack.capture(batches[0], batches[1])   # the two resident input buffers ARE the two batches: no copy per step
+            stack.capture(*batches[:stack.ring])    # the resident input buffers ARE the batches: no copy per step
             step = stack.replay
         else:
             stack.capture(batches[0])
 
             def step():                              # every step alone: the one input buffer takes the next batch
-                stack.replay(batches[count[0] & 1])
+                stack.replay(batches[count[0] % len(batches)])
                 count[0] += 1
         for _ in range(warmup):
             step()
@@ -452,17 +496,24 @@ def main():
         """the buffers the timed steps left behind against the oracle, then ONE more step and the same again: the second pass
         sees the other batch in every role (sampled / grouped), so each of the two distinct inputs is verified end to end"""
         mism = {}
-        for which in range(2):
+        nb = len(batches)
+        for which in range(stack.ring if stack.pipelined else 2):
             torch.cuda.synchronize()
+            prev2 = None
             if stack.pipelined and not args.no_graph:
-                s_par, g_par = stack.owners()
-                cur, prev = stack.inputs[s_par], stack.inputs[g_par]
-            else:   # the last step consumed batches[(steps - 1) & 1]; pipelined eager steps grouped the one before it
+                if stack.stages == 3:
+                    s1, s2, g = stack.owners3()
+                    cur, prev, prev2 = stack.inputs[s1], stack.inputs[s2], stack.inputs[g]
+                else:
+                    s_par, g_par = stack.owners()
+                    cur, prev = stack.inputs[s_par], stack.inputs[g_par]
+            else:   # the last step consumed batches[(steps - 1) % nb]; pipelined eager steps worked on the ones before it too
                 done = stack.replays if stack.pipelined else step_count(step)
-                cur = batches[(done - 1) & 1]
-                prev = batches[done & 1] if stack.pipelined else None
+                cur = batches[(done - 1) % nb]
+                prev = batches[(done - 2) % nb] if stack.pipelined else None
+                prev2 = batches[(done - 3) % nb] if stack.stages == 3 else None
             for s_ in scenes:
-                bad = verify_scene(stack, cur, s_, prev_xyz=prev)
+                bad = verify_scene(stack, cur, s_, prev_xyz=prev, prev2_xyz=prev2)
                 if bad:
                     mism["pass %d scene %d" % (which, s_)] = bad
             step()
@@ -486,7 +537,7 @@ def main():
 
     elapsed, stack, batches, step = time_stack(args.batch, args.steps, args.warmup)
     xyz = batches[0]
-    stack_s_levels, stack_chain = stack.s_query_levels, stack.chain
+    stack_s_levels, stack_chain, stack_stages = stack.s_query_levels, stack.chain, stack.stages
     reduce_dev = dev if dist.is_initialized() and dist.get_backend() == "nccl" else "cpu"
     elapsed_own = elapsed
     elapsed = scene_shard.max_over_ranks(elapsed, device=reduce_dev)
@@ -505,10 +556,10 @@ def main():
         picks = sorted({0, args.batch - 1} if args.verify_scenes > 1 else {0})
         picks += [s_ for s_ in range(1, args.batch - 1)][:max(0, args.verify_scenes - len(picks))]
         mism = verify_stack(stack, batches, step, picks)
-        verification = {"verified": not mism, "scenes": picks, "distinct_inputs": 2, "mismatches": mism,
+        verification = {"verified": not mism, "scenes": picks, "distinct_inputs": len(batches), "mismatches": mism,
                         "checked": "fps_idx, centres, ball-query idx and grouped tensors of all %d levels%s of the timed buffers "
-                                   "(%s; two different resident batches alternate, each checked as the sampled and as the grouped "
-                                   "one) vs oracle/epnet_oracle.c: identical"
+                                   "(%s; different resident batches rotate through the steps, each checked in every role -- sampled, "
+                                   "queried, grouped) vs oracle/epnet_oracle.c: identical"
                                    % (len(stack.levels), " + three_nn / three_interpolate (1e-5)" if args.with_fp else "",
                                       "pipelined HIP-graph replays" if (args.pipelined and not args.no_graph) else
                                       ("HIP-graph replays" if not args.no_graph else "eager steps"))}
@@ -593,7 +644,7 @@ def main():
                 "scenes_per_gpu": batch, "points_per_scene": pts, "steps": steps, "ms_per_step": round(e / steps * 1e3, 4),
                 "points_per_s": round(rate, 1), "stack_algorithmic_GBps": round(rate / pts * nbytes / 1e9, 2),
                 "stack_hbm_frac": round(rate / pts * nbytes / 1e9 / HBM_PEAK_GBS, 6),
-                "verified": None if bad is None else not bad, "mismatches": bad or {}, "distinct_inputs": 2,
+                "verified": None if bad is None else not bad, "mismatches": bad or {}, "distinct_inputs": len(bt),
                 "identity_share_levels_2_up": share, "workload": note}
             del st, bt, stp
             torch.cuda.empty_cache()
@@ -649,7 +700,7 @@ def main():
             "config": {"workload": "%d x %d-pt %s scenes per GPU per step through %s, %s launch"
                                    % (args.batch, args.points, args.kind, shape, "eager" if args.no_graph else "HIP-graph"),
                        "baseline_config": args.config, "levels": levels,
-                       "scenes_per_gpu": args.batch, "software_pipelined": bool(args.pipelined),
+                       "scenes_per_gpu": args.batch, "software_pipelined": bool(args.pipelined), "pipeline_stages": stack_stages,
                        "ball_queries_in_stage_s_levels": [v + 1 for v in sorted(stack_s_levels)], "points_per_scene": args.points, "parallelism": "scene-parallel x%d" % world},
             "points_per_s_per_gpu": round(value / world, 1),
             "stack_algorithmic_GBps_per_gpu": round(stack_gbs, 2), "stack_hbm_frac": round(stack_gbs / HBM_PEAK_GBS, 6),

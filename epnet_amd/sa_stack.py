@@ -77,8 +77,16 @@ def fp_algorithmic_bytes(fp=RPN_FP):
 class SAStack:
     def __init__(self, batch, n=16384, device="cuda", npoints=RPN_NPOINTS, radii=RPN_RADII, nsamples=RPN_NSAMPLES,
                  feat_channels=RPN_FEAT_CHANNELS, with_fp=False, fp=RPN_FP, seed=0, overlap=True, fused=True,
-                 shared_index=True, pipelined=False, fused_sampling=False, queries_in_s=None, s_query_levels=None):
+                 shared_index=True, pipelined=False, fused_sampling=False, queries_in_s=None, s_query_levels=None, stages=None):
         self.batch, self.n = batch, n
+        # pipelined with THREE stages (stages=3; EPNET_SA_STAGES): the sampling chain is itself split in two -- S1, the level-1
+        # sampling (2.1 of stage S's 3.1 ms: a latency-bound chain of one workgroup per scene), and S2, everything behind it
+        # (levels 2-4, the ball queries, the FP neighbour searches: 17 short dispatches that wait for a place beside the wide kernels)
+        # -- so that a step runs S1 of batch k beside S2 of batch k-1 beside G of batch k-2 from a ring of three buffer sets
+        if stages is None:
+            stages = int(os.environ.get("EPNET_SA_STAGES", "2"))
+        self.stages = 3 if (pipelined and stages == 3 and fused_sampling and fused and shared_index) else (2 if pipelined else 1)
+        self.ring = self.stages   # buffer sets (and resident input clouds) the schedule rotates through
         # overlap: FPS/gather of level l+1 depend only on the centres of level l (never on features), so
         # the sampling chain runs ahead on the launch stream while ball query + grouping of each level
         # follow on a second HIP stream
@@ -111,6 +119,8 @@ class SAStack:
             chosen = every if queries_in_s else frozenset()
         elif env_lv is not None:
             chosen = frozenset(int(v) for v in env_lv.split(",") if v.strip())
+        elif self.stages == 3:
+            chosen = every   # stage S2 has the room (and the grouping stage is the longest one)
         elif env_q == 2 or (env_q == 1 and with_fp):
             chosen = every
         elif env_q == 1 and batch * n >= 240 * 16384:
@@ -147,7 +157,10 @@ class SAStack:
                 "n": cur, "m": m, "c": c,
                 "xyz_t": torch.empty((batch, 3, cur), dtype=f32, device=dev),
                 "temp": torch.empty((batch, cur), dtype=f32, device=dev),
-                "fps_idx": torch.empty((batch, m), dtype=i32, device=dev),
+                # (two stages: the sampling chain of one batch writes all levels in one go -- one tensor; three: S1 of batch k writes
+                # level 1 while S2 of batch k-1 still reads its own)
+                "fps_idx_sets": ([torch.empty((batch, m), dtype=i32, device=dev) for _ in range(3)] if self.stages == 3 else None),
+                "fps_idx": None,
                 "new_xyz_t": torch.empty((batch, 3, m), dtype=f32, device=dev),
                 # what G reads from S, one set per pipeline parity
                 "sets": [{"new_xyz": torch.empty((batch, m, 3), dtype=f32, device=dev),
@@ -156,13 +169,13 @@ class SAStack:
                           # the last level's centres have no next level to index them: their own index for the ordered ball query
                           "centre_index": (torch.empty((ext.scene_index_bytes(batch, m),), dtype=torch.uint8, device=dev)
                                            if (shared_index and lvl + 1 == len(npoints) and ext.scene_index_bytes(batch, m)) else None)}
-                         for _ in range(2 if pipelined else 1)],
+                         for _ in range(self.ring)],
                 "features": (torch.randn((batch, c, cur), generator=g, dtype=f32).to(dev) if c else None),
                 "scales": [],
             }
             for radius, ns in zip(radii[lvl], nsamples[lvl]):
                 S = {"radius": radius, "ns": ns, "idx": torch.empty((batch, m, ns), dtype=i32, device=dev)}
-                S["idx_sets"] = [S["idx"]] + ([torch.empty((batch, m, ns), dtype=i32, device=dev)]
+                S["idx_sets"] = [S["idx"]] + ([torch.empty((batch, m, ns), dtype=i32, device=dev) for _ in range(self.ring - 1)]
                                               if lvl in self.s_query_levels else [])
                 if fused:
                     S["grouped"] = torch.empty((batch, 3 + c, m, ns), dtype=f32, device=dev)
@@ -170,6 +183,10 @@ class SAStack:
                     S["grouped_xyz"] = torch.empty((batch, 3, m, ns), dtype=f32, device=dev)
                     S["grouped_feat"] = torch.empty((batch, c, m, ns), dtype=f32, device=dev) if c else None
                 L["scales"].append(S)
+            if L["fps_idx_sets"] is None:
+                one = torch.empty((batch, m), dtype=i32, device=dev)
+                L["fps_idx_sets"] = [one] * self.ring
+            L["fps_idx"] = L["fps_idx_sets"][0]
             self.levels.append(L)
             cur = m
         self.fp_bufs = []
@@ -177,7 +194,7 @@ class SAStack:
             for c, m, nn_ in fp:
                 sets = [{"dist2": torch.empty((batch, nn_, 3), dtype=f32, device=dev),
                          "idx": torch.empty((batch, nn_, 3), dtype=i32, device=dev),
-                         "weight": torch.empty((batch, nn_, 3), dtype=f32, device=dev)} for _ in range(2 if pipelined else 1)]
+                         "weight": torch.empty((batch, nn_, 3), dtype=f32, device=dev)} for _ in range(self.ring)]
                 self.fp_bufs.append({
                     "c": c, "m": m, "n": nn_,
                     "known_feats": torch.randn((batch, c, m), generator=g, dtype=f32).to(dev),
@@ -209,15 +226,27 @@ class SAStack:
         by stage S (fps_idx, sets[p], the idx_sets[p] of the levels in s_query_levels, the FP search sets[p]) hold the batch
         of the LAST step; buffers written by stage G (grouped tensors, the single idx tensors of the other levels, the
         interpolation outputs) and the other parity's sets hold the batch of the step BEFORE it."""
+        if self.stages == 3:
+            raise RuntimeError("three stages: see owners3()")
         p = (self.replays - 1) & 1 if self.pipelined else 0
         return p, (1 - p if self.pipelined else 0)
+
+    def owners3(self):
+        """three stages, after `replays` >= 1 steps (the last one was step k = replays - 1): the buffer sets (slots of the ring) the
+        last step's stages worked on -- (S1: level-1 sampling of batch k, S2: the rest of the sampling chain + queries + searches of
+        batch k-1, G: groupings / interpolation of batch k-2). Slot S1 holds batch k's level-1 index, indices and prefix only (its
+        other buffers still belong to batch k-3); slot S2 everything stage S writes; slot G that and, with the single-buffered
+        outputs of stage G, the COMPLETE results of batch k-2."""
+        k = self.replays - 1
+        return k % 3, (k - 1) % 3, (k - 2) % 3
 
     def chain_identity_share(self, parity=None):
         """per level 2.. of the pyramid: the share of scenes whose sampling took the identity (the level above reported a tie-free
         prefix at least as long as this level's sample count) in the last step that sampled into set `parity`"""
         if not self.chain:
             return None
-        parity = self.owners()[0] if parity is None else parity
+        if parity is None:
+            parity = self.owners3()[1] if self.stages == 3 else self.owners()[0]
         out = []
         for lvl in range(1, len(self.levels)):
             known = self.levels[lvl - 1]["sets"][parity if self.pipelined else 0]["prefix"]
@@ -236,7 +265,7 @@ class SAStack:
         if pending is not None and pending[1:] == (lvl - 1, parity):   # cur_xyz has not been written yet: gather + index in one
             src_xyz, _, _ = pending
             prev = self.levels[lvl - 1]
-            ext.scene_index_build_gathered_wrapper(b, prev["n"], n, src_xyz, prev["fps_idx"], cur_xyz, P["index"])
+            ext.scene_index_build_gathered_wrapper(b, prev["n"], n, src_xyz, prev["fps_idx_sets"][parity], cur_xyz, P["index"])
         elif P["index"] is not None and not index_built:
             ext.scene_index_build_wrapper(b, n, cur_xyz, P["index"])
         if self.fused_sampling:   # FPS + gather of the centres in one kernel (epnet_sample_centres)
@@ -248,20 +277,20 @@ class SAStack:
                 nxt_L = self.levels[lvl + 1] if lvl + 1 < len(self.levels) else None
                 defer = (defer_ok and self.fuse_gather and self.fused and nxt_L is not None
                          and nxt_L["sets"][parity]["index"] is not None and 1024 <= m <= 16384)
-                ext.sample_centres_wrapper(b, n, m, cur_xyz, P["index"], L["fps_idx"], None if defer else P["new_xyz"],
+                ext.sample_centres_wrapper(b, n, m, cur_xyz, P["index"], L["fps_idx_sets"][parity], None if defer else P["new_xyz"],
                                            prefix_in, P["prefix"], nxt)
                 if defer:
                     self._deferred = (cur_xyz, lvl, parity)
             else:
-                ext.sample_centres_wrapper(b, n, m, cur_xyz, P["index"], L["fps_idx"], P["new_xyz"])
+                ext.sample_centres_wrapper(b, n, m, cur_xyz, P["index"], L["fps_idx_sets"][parity], P["new_xyz"])
         else:                     # the reference module's sequence, op by op
             L["xyz_t"].copy_(cur_xyz.transpose(1, 2))            # pointnet2_modules.py:30
             L["temp"].fill_(1e10)                                # pointnet2_utils.py:26
             if P["index"] is not None:
-                ext.furthest_point_sampling_indexed_wrapper(b, n, m, cur_xyz, P["index"], L["temp"], L["fps_idx"])
+                ext.furthest_point_sampling_indexed_wrapper(b, n, m, cur_xyz, P["index"], L["temp"], L["fps_idx_sets"][parity])
             else:
-                ext.furthest_point_sampling_wrapper(b, n, m, cur_xyz, L["temp"], L["fps_idx"])
-            ext.gather_points_wrapper(b, 3, n, m, L["xyz_t"], L["fps_idx"], L["new_xyz_t"])
+                ext.furthest_point_sampling_wrapper(b, n, m, cur_xyz, L["temp"], L["fps_idx_sets"][parity])
+            ext.gather_points_wrapper(b, 3, n, m, L["xyz_t"], L["fps_idx_sets"][parity], L["new_xyz_t"])
             P["new_xyz"].copy_(L["new_xyz_t"].transpose(1, 2))    # pointnet2_modules.py:42-45
         return P["new_xyz"]
 
@@ -420,6 +449,60 @@ class SAStack:
             self._group_scale(first, S, prev_xyz, 1 - parity)
         main.wait_stream(side)
 
+    def run_pipelined3(self, clouds, step):
+        """one steady-state step of the three-stage schedule. clouds[slot] = the resident input cloud of every ring slot; this step
+        samples level 1 of clouds[p] (S1), finishes the sampling chain / queries / searches of clouds[q] (S2: the batch of the step
+        before) and groups clouds[r] (G: the batch of two steps before), p, q, r = step, step - 1, step - 2 mod 3. Three streams,
+        forked behind the level-1 index build and joined at the end of the step: every stage reads only what the step before left."""
+        p, q, r = step % 3, (step - 1) % 3, (step - 2) % 3
+        main = torch.cuda.current_stream(clouds[p].device)
+        side = self._side_stream(clouds[p].device)
+        third = self._third_stream(clouds[p].device)
+        first = self.levels[0]
+        # built before the other stages are issued: a one-workgroup-per-scene kernel with 64 KB of LDS cannot find a free CU once
+        # the wide kernels are in flight
+        ext.scene_index_build_wrapper(self.batch, first["n"], clouds[p], first["sets"][p]["index"])
+        forked = torch.cuda.Event()
+        forked.record(main)
+        # ---- S1 (this stream): the level-1 rounds of batch `step`
+        self._deferred = None
+        self._sample_level(first, clouds[p], p, index_built=True, defer_ok=True)
+        s1_deferred = self._deferred is not None   # (a property of the configuration: the same in every step)
+        self._deferred = None
+        # ---- G: groupings (and interpolation) of the batch of two steps before
+        side.wait_event(forked)
+        with torch.cuda.stream(side):
+            inputs = [clouds[r]] + [L["sets"][r]["new_xyz"] for L in self.levels[:-1]]
+            order = list(zip(self.levels, inputs))
+            for lvl, (L, cur) in enumerate(order[1:], start=1):   # feature gathers first (few registers: they share the CUs with S1)
+                if lvl not in self.s_query_levels:
+                    self._query_level(L, cur, r)
+                self._group_scales(L, cur, r)
+            if 0 not in self.s_query_levels:
+                self._query_level(first, clouds[r], r)
+            self._group_scales(first, clouds[r], r)
+            if self.with_fp:
+                self._interpolate_fp(r)
+        # ---- S2: levels 2.. of the sampling chain, the ball queries and the FP searches of the batch of the step before
+        third.wait_event(forked)
+        with torch.cuda.stream(third):
+            # what S1 of the step before left undone: the level-1 centres are gathered by level 2's index build
+            self._deferred = (clouds[q], 0, q) if s1_deferred else None
+            cur = first["sets"][q]["new_xyz"]
+            for L in self.levels[1:]:
+                cur = self._sample_level(L, cur, q, defer_ok=True)
+            self._deferred = None
+            if self.with_fp:
+                self._search_fp(clouds[q], q)
+            self._queries_of(clouds[q], q)
+        main.wait_stream(side)
+        main.wait_stream(third)
+
+    def _third_stream(self, device):
+        if getattr(self, "third", None) is None:
+            self.third = torch.cuda.Stream(device=device)
+        return self.third
+
     def _queries_of(self, xyz, parity):
         """the ball queries of the levels in s_query_levels for the batch whose centres / indices are in set `parity`"""
         cur = xyz
@@ -463,28 +546,35 @@ class SAStack:
     def _prime(self, clouds):
         """before the first pipelined step: stage S of clouds[p] into set p for BOTH parities, so that the first step's stage G
         (the "previous batch" = clouds[1]) reads valid centres and indices, never uninitialised memory"""
-        for parity in (0, 1):
+        for parity in range(self.ring):
             xyz = cur = clouds[parity]
+            self._deferred = None
             for L in self.levels:
                 cur = self._sample_level(L, cur, parity, defer_ok=True)
+            self._deferred = None
             if self.with_fp:
                 self._search_fp(xyz, parity)
             if self.s_query_levels:
                 self._queries_of(xyz, parity)
 
     def _step_eager(self, k):
-        if self.pipelined:
+        if self.stages == 3:
+            self.run_pipelined3(self.inputs, k)
+        elif self.pipelined:
             self.run_pipelined(self.inputs[k & 1], self.inputs[1 - (k & 1)], k)
         else:
             self.run(self.inputs[0])
 
-    def capture(self, xyz, xyz_other=None):
-        """capture the step into HIP graph(s) (torch.cuda.CUDAGraph); replay with self.replay(). Pipelined: two graphs, one per
-        parity, replayed alternately; graph p samples inputs[p] and groups inputs[1 - p]. `xyz` fills inputs[0], `xyz_other`
-        (default: the same cloud) inputs[1]: the batch the FIRST replay's grouping stage sees as "the step before"."""
+    def capture(self, xyz, xyz_other=None, xyz_third=None):
+        """capture the step into HIP graph(s) (torch.cuda.CUDAGraph); replay with self.replay(). Pipelined: one graph per ring slot
+        (two stages: two, three stages: three), replayed in turn; graph p samples inputs[p] and works on the other slot(s) for the
+        batch(es) before. `xyz` fills inputs[0], `xyz_other` / `xyz_third` (default: the same cloud) inputs[1] / inputs[2]: the
+        batches the FIRST replays see as "the step(s) before"."""
         self.inputs = [xyz.clone()]
         if self.pipelined:
             self.inputs.append((xyz if xyz_other is None else xyz_other).clone())
+        if self.stages == 3:
+            self.inputs.append((xyz if xyz_third is None else xyz_third).clone())
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         period = 1
@@ -492,7 +582,7 @@ class SAStack:
             if self.pipelined:
                 self._prime(self.inputs)
         if self.pipelined:
-            period = 2   # one graph per parity
+            period = self.ring   # one graph per ring slot
         with torch.cuda.stream(s):
             for k in range(max(2, period)):   # warm-up outside capture; fills every buffer of the rotation
                 self._step_eager(k)
@@ -519,7 +609,16 @@ class SAStack:
     def step(self, xyz):
         """eager (no graph) step on the caller's own tensor. Pipelined: stage S of `xyz` beside stage G of the cloud handed to
         the step before, which the caller therefore leaves untouched until this step has been issued (stream order does the rest)."""
-        if self.pipelined:
+        if self.stages == 3:
+            if self._prev_xyz is None:
+                self._prime([xyz, xyz, xyz])
+                self._eager_clouds = [xyz, xyz, xyz]
+                self._prev_xyz = xyz
+                self.replays = 0
+            self._eager_clouds[self.replays % 3] = xyz    # (the clouds of the two steps before stay referenced here)
+            self.run_pipelined3(self._eager_clouds, self.replays)
+            self.replays += 1
+        elif self.pipelined:
             if self._prev_xyz is None:
                 self._prime([xyz, xyz])
                 self._prev_xyz = xyz

@@ -74,6 +74,71 @@ def test_pipelined_graphs_on_a_stream_of_different_batches(oracle, with_fp, in_s
     assert "level1.fps_idx" in wrong and not any(name.endswith("grouped") for name in wrong)
 
 
+@pytest.mark.parametrize("with_fp,in_s", [(False, None), (True, None), (False, (1, 2, 3))])
+def test_three_stage_graphs_on_a_stream_of_different_batches(oracle, with_fp, in_s):
+    """stages=3: level-1 sampling of batch k beside the rest of the sampling chain + queries of batch k-1 beside the grouping of
+    batch k-2, three graphs over a ring of three buffer sets. After step k batch k-2 is complete; the slots of the younger
+    batches hold what their stages have written so far (bench.verify_scene knows which: SAStack.owners3())"""
+    import bench
+    from epnet_amd import sa_stack
+    b, n = 2, 16384
+    kinds, batches = _batches(oracle, b, n)
+    stack = sa_stack.SAStack(b, n=n, device=DEV, with_fp=with_fp, seed=5, pipelined=True, fused_sampling=True, s_query_levels=in_s, stages=3)
+    assert stack.stages == 3 and stack.ring == 3 and len(stack.levels[0]["sets"]) == 3
+    assert stack.s_query_levels == (frozenset(range(4)) if in_s is None else frozenset(in_s))
+    stack.capture(batches[0])
+    _poison(stack)
+    stack.replay(batches[0])
+    stack.replay(batches[1])
+    for k in range(2, len(batches)):
+        stack.replay(batches[k])               # samples level 1 of batch k, finishes the chain of batch k-1, groups batch k-2
+        torch.cuda.synchronize()
+        for scene in range(b):
+            bad = bench.verify_scene(stack, batches[k], scene, prev_xyz=batches[k - 1], prev2_xyz=batches[k - 2])
+            assert bad == [], (kinds[k - 2], kinds[k - 1], kinds[k], scene, bad)
+    # the check tells the three batches apart
+    k = len(batches) - 1
+    wrong = bench.verify_scene(stack, batches[k], 0, prev_xyz=batches[k - 1], prev2_xyz=batches[0])
+    assert any(name.endswith("grouped") for name in wrong) and not any(name.startswith("level1.fps_idx[set %d]" % (k % 3)) for name in wrong)
+    wrong = bench.verify_scene(stack, batches[0], 0, prev_xyz=batches[k - 1], prev2_xyz=batches[k - 2])
+    assert wrong == ["level1.fps_idx[set %d]" % (k % 3)]       # all a slot holds of the youngest batch is its level-1 sampling
+
+
+def test_three_stage_eager_steps(oracle):
+    import bench
+    from epnet_amd import sa_stack
+    b, n = 1, 16384
+    kinds, batches = _batches(oracle, b, n)
+    stack = sa_stack.SAStack(b, n=n, device=DEV, with_fp=True, seed=5, pipelined=True, fused_sampling=True, stages=3)
+    stack.step(batches[0])
+    stack.step(batches[1])
+    for L in stack.levels:               # (stage G's outputs only: the sampling stages of these batches have run already)
+        for S in L["scales"]:
+            S["grouped"].fill_(float("nan"))
+    for k in range(2, 5):
+        stack.step(batches[k])
+        torch.cuda.synchronize()
+        assert bench.verify_scene(stack, batches[k], 0, prev_xyz=batches[k - 1], prev2_xyz=batches[k - 2]) == [], kinds[k - 2]
+
+
+def test_three_stages_on_one_level_config5(oracle):
+    """BASELINE config 5 (one level, 65536 points): S1 = sampling, S2 = the ball query, G = the grouping"""
+    import bench
+    from epnet_amd import sa_stack, synth
+    cfg = sa_stack.CONFIGS[5]
+    b = 1
+    batches = [synth.scenes(kind, b, cfg["n"], seed=70 + i).to(DEV) for i, kind in enumerate(("kitti", "ubox", "kitti", "kitti_q"))]
+    stack = sa_stack.SAStack(b, n=cfg["n"], device=DEV, npoints=cfg["npoints"], radii=cfg["radii"], nsamples=cfg["nsamples"],
+                             feat_channels=cfg["feat_channels"], seed=6, pipelined=True, fused_sampling=True, stages=3)
+    stack.capture(batches[0])
+    _poison(stack)
+    for k in range(len(batches)):
+        stack.replay(batches[k])
+        torch.cuda.synchronize()
+        if k >= 2:
+            assert bench.verify_scene(stack, batches[k], 0, prev_xyz=batches[k - 1], prev2_xyz=batches[k - 2]) == []
+
+
 def test_loader_fills_the_input_buffer_in_place(oracle):
     """no copy in replay(): the producer writes the next batch into stack.input_buffer() (stream-ordered behind the last replay)"""
     import bench
