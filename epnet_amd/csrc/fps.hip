@@ -1160,7 +1160,7 @@ static void launch_gather_centres(int b, int n, int m, const float *xyz, const i
 }
 
 // shared by the two entry points below; new_xyz may be NULL
-static int fps_over_index(int b, int n, int m, const float *xyz, const void *index, size_t index_bytes, float *temp, int *idx,
+static int fps_over_index(int b, int n, int m, const float *xyz, void *index, size_t index_bytes, float *temp, int *idx,
                           float *new_xyz, hipStream_t s, const int *skip = nullptr, int *prefix_out = nullptr,
                           int prefix_cap = 0x7fffffff) {
     const size_t need = scene_index_bytes(b, n);
@@ -1231,7 +1231,7 @@ static int fps_over_index(int b, int n, int m, const float *xyz, const void *ind
     return check_launch("sample_centres gather");
 }
 
-extern "C" int epnet_furthest_point_sampling_indexed(int b, int n, int m, const float *xyz, const void *index,
+extern "C" int epnet_furthest_point_sampling_indexed(int b, int n, int m, const float *xyz, void *index,
                                                      size_t index_bytes, float *temp, int *idx,
                                                      epnet_stream_t stream) {
     return fps_over_index(b, n, m, xyz, index, index_bytes, temp, idx, nullptr, (hipStream_t)stream);
@@ -1241,7 +1241,7 @@ extern "C" int epnet_furthest_point_sampling_indexed(int b, int n, int m, const 
 // (pointnet2_modules.py:39-45: furthest_point_sample, then gather_operation on the flipped cloud, flipped back):
 // idx (B,M) and new_xyz (B,M,3) = xyz[b, idx[b,i], :]. temp: running-distance scratch (B,N) or NULL (then every
 // distance starts at 1e10 as pointnet2_utils.py:26 sets it; allowed for 64 <= n <= 16384); index may be NULL.
-extern "C" int epnet_sample_centres(int b, int n, int m, const float *xyz, const void *index, size_t index_bytes,
+extern "C" int epnet_sample_centres(int b, int n, int m, const float *xyz, void *index, size_t index_bytes,
                                     float *temp, int *idx, float *new_xyz, epnet_stream_t stream) {
     EPNET_REQUIRE(b >= 0 && n >= 1 && m >= 0);
     if (b == 0 || m == 0) return EPNET_OK;
@@ -1258,7 +1258,7 @@ extern "C" int epnet_sample_centres(int b, int n, int m, const float *xyz, const
 // the rounds.
 // prefix_out[b] (or NULL) receives the same knowledge about THIS sampling's output (0 where the kernel cannot tell), looked
 // for during the first prefix_cap rounds only (<= 0: all rounds) -- the next level's sample count is all anybody will ask for.
-extern "C" int epnet_sample_centres_chain(int b, int n, int m, const float *xyz, const void *index, size_t index_bytes,
+extern "C" int epnet_sample_centres_chain(int b, int n, int m, const float *xyz, void *index, size_t index_bytes,
                                           float *temp, int *idx, float *new_xyz, const int *prefix_in, int *prefix_out,
                                           int prefix_cap, epnet_stream_t stream) {
     EPNET_REQUIRE(b >= 0 && n >= 1 && m >= 0);

@@ -209,9 +209,9 @@ inline size_t scene_index_bytes(int b, int n) {
     const size_t np = (size_t)scene_index_np(n);
     return (size_t)b * (np * sizeof(float4) + (np / 64 + np / 256) * 6 * sizeof(float) + (n > 16384 ? np * sizeof(float) : 0));
 }
-inline float *scene_index_sampling_scratch(int b, int n, const void *index) {
+inline float *scene_index_sampling_scratch(int b, int n, void *index) {
     const size_t np = (size_t)scene_index_np(n);
-    return (float *)((char *)const_cast<void *>(index) + (size_t)b * (np * sizeof(float4) + (np / 64 + np / 256) * 6 * sizeof(float)));
+    return (float *)((char *)index + (size_t)b * (np * sizeof(float4) + (np / 64 + np / 256) * 6 * sizeof(float)));
 }
 
 // defined in ball_query.hip

@@ -8,6 +8,7 @@ plumbing: outputs are allocated on the INPUT's device (the reference uses
 ``torch.cuda.FloatTensor(...)``, i.e. whatever device is current), and errors raise instead of
 killing the process.
 """
+import os
 import threading
 from typing import Optional, Tuple
 
@@ -100,7 +101,14 @@ def scene_index(xyz: torch.Tensor, cached_only: bool = False) -> Optional[torch.
     return index
 
 
-def sample_and_gather(xyz: torch.Tensor, npoint: int, index: Optional[torch.Tensor] = None, next_npoint: int = 0):
+def _chain_by_attribute() -> bool:
+    """EPNET_SA_CHAIN=0 switches the attribute-carried knowledge off (every level runs its rounds unless the caller passes
+    `prefix=` explicitly, as sample_pyramid does)"""
+    return os.environ.get("EPNET_SA_CHAIN", "1") != "0"
+
+
+def sample_and_gather(xyz: torch.Tensor, npoint: int, index: Optional[torch.Tensor] = None, next_npoint: int = 0,
+                      prefix: Optional[torch.Tensor] = None, with_prefix: bool = False):
     """the head of an SA module in one call: ``idx = furthest_point_sample(xyz, npoint)`` and
     ``new_xyz = gather_operation(xyz.transpose(1, 2), idx).transpose(1, 2)`` (pointnet2_modules.py:39-45) -- the
     sampling kernel has every selected point in registers, so the centres come with the indices. Same values;
@@ -110,22 +118,30 @@ def sample_and_gather(xyz: torch.Tensor, npoint: int, index: Optional[torch.Tens
     tensors, only while their version counter stands) for how many leading rounds the sampling was unambiguous. When such
     centres are sampled again -- the next SA level -- scenes whose first npoint rounds were unambiguous get
     ``idx = 0 .. npoint-1``: furthest point sampling is nested (include/epnet_ops.h, epnet_sample_centres_chain), so that IS
-    what the rounds would compute. Three of the four sampling kernels of the RPN pyramid disappear that way."""
+    what the rounds would compute. Three of the four sampling kernels of the RPN pyramid disappear that way.
+
+    ``prefix`` (int32 (B,), the prefix_out of the sampling that produced ``xyz``) hands that knowledge over EXPLICITLY and
+    ``with_prefix=True`` returns this call's own as a third result: sample_pyramid chains its levels that way, nothing is read
+    from or attached to a tensor. The attribute form serves callers that chain SA modules one by one; its hazard: the centres
+    are handed back to the caller, and a write that does not move the version counter (``new_xyz.data.copy_()``, ``set_()``, a
+    foreign extension writing through ``data_ptr()``) leaves the attribute standing on changed coordinates -- such callers set
+    EPNET_SA_CHAIN=0."""
     assert xyz.is_contiguous()
     batch, n = xyz.shape[0], xyz.shape[1]
     idx = _new(xyz, (batch, npoint), torch.int32)
     new_xyz = _new(xyz, (batch, npoint, 3))
-    prefix_in = None
-    known = getattr(xyz, "_epnet_fps_prefix", None)
+    prefix_in = prefix
+    by_attribute = prefix is None and not with_prefix and _chain_by_attribute()
+    known = getattr(xyz, "_epnet_fps_prefix", None) if by_attribute else None
     if known is not None and getattr(xyz, "_epnet_owned", False) and not xyz.is_inference() and known[1] == xyz._version \
             and known[2] == _capture_epoch():
         prefix_in = known[0]
     prefix_out = _new(xyz, (batch,), torch.int32)
     _ext.sample_centres_wrapper(batch, n, npoint, xyz.detach(), index, idx, new_xyz, prefix_in, prefix_out, int(next_npoint))
     new_xyz = _own(new_xyz)
-    if not new_xyz.is_inference():
+    if by_attribute and not new_xyz.is_inference():
         new_xyz._epnet_fps_prefix = (prefix_out, new_xyz._version, _capture_epoch())
-    return idx, new_xyz
+    return (idx, new_xyz, prefix_out) if with_prefix else (idx, new_xyz)
 
 
 _PYRAMID_STREAMS = {}
@@ -148,10 +164,12 @@ def sample_pyramid(xyz: torch.Tensor, npoints):
     levels = []
     with torch.cuda.stream(side):
         cur = xyz.detach()
+        known = None                               # the chain of tie-free round counts, handed from level to level right here
         for k, m in enumerate(npoints):
             src = xyz if k == 0 else cur          # the tensor object the SA module of this level will receive
             index = scene_index(src)
-            idx, new_xyz = sample_and_gather(src, int(m), index, int(npoints[k + 1]) if k + 1 < len(npoints) else 1)
+            idx, new_xyz, known = sample_and_gather(src, int(m), index, int(npoints[k + 1]) if k + 1 < len(npoints) else 1,
+                                                    prefix=known, with_prefix=True)
             event = torch.cuda.Event()
             event.record(side)
             for t in (idx, new_xyz, index):       # allocated on the side stream, consumed on the caller's

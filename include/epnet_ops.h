@@ -201,7 +201,8 @@ int epnet_feature_gather_grad(int b, int c, int h, int w, int n, int align_corne
  * epnet_scene_index_bytes returns 0 where no index applies; the *_indexed entry points then (or with
  * index == NULL) run the plain path. For n > 16384 the last part of the buffer is scratch of the sampling kernel
  * (its running distances in sorted order): two samplings over ONE index buffer must not run concurrently there;
- * the ball queries and three_nn never touch that part.
+ * the ball queries and three_nn never touch that part. The three sampling entry points therefore take the index as a NON-const
+ * pointer (they write that tail; the sorted points and boxes in front of it are only read), everybody else as const.
  * -------------------------------------------------------------------------------------- */
 size_t epnet_scene_index_bytes(int b, int n);
 int epnet_scene_index_build(int b, int n, const float *xyz, void *index, size_t index_bytes, epnet_stream_t stream);
@@ -211,12 +212,12 @@ int epnet_scene_index_build(int b, int n, const float *xyz, void *index, size_t 
 int epnet_scene_index_build_gathered(int b, int n_src, int n, const float *xyz_src, const int *idx, float *gathered, void *index,
                                      size_t index_bytes, epnet_stream_t stream);
 /* same contract as epnet_furthest_point_sampling (sampling_gpu.cu:211-253) */
-int epnet_furthest_point_sampling_indexed(int b, int n, int m, const float *xyz, const void *index,
+int epnet_furthest_point_sampling_indexed(int b, int n, int m, const float *xyz, void *index,
                                           size_t index_bytes, float *temp, int *idx, epnet_stream_t stream);
 /* the head of an SA module in one call (pointnet2_modules.py:39-45): furthest point sampling from a fresh state
  * (all running distances 1e10, pointnet2_utils.py:26) and new_xyz (b,m,3) = the selected rows of xyz. temp = scratch
  * (b,n) or NULL (allowed for 64 <= n <= 16384); index = scene index of xyz or NULL */
-int epnet_sample_centres(int b, int n, int m, const float *xyz, const void *index, size_t index_bytes, float *temp,
+int epnet_sample_centres(int b, int n, int m, const float *xyz, void *index, size_t index_bytes, float *temp,
                          int *idx, float *new_xyz, epnet_stream_t stream);
 /* epnet_sample_centres for the levels of a sampling pyramid (SA level l+1 samples the centres of level l). Furthest point
  * sampling is nested: while every round's maximum is unique, the first m samples of a furthest-point sequence ARE the
@@ -229,7 +230,7 @@ int epnet_sample_centres(int b, int n, int m, const float *xyz, const void *inde
  * run the rounds. prefix_out (b ints or NULL): the same knowledge about this call's output (at least that many rounds), 0 where
  * the kernel cannot tell; ties are looked for during the first prefix_cap rounds only (<= 0: all) -- pass the next level's m.
  * new_xyz may be NULL here (indices only: the centres then come out of epnet_scene_index_build_gathered of the next level). */
-int epnet_sample_centres_chain(int b, int n, int m, const float *xyz, const void *index, size_t index_bytes, float *temp,
+int epnet_sample_centres_chain(int b, int n, int m, const float *xyz, void *index, size_t index_bytes, float *temp,
                                int *idx, float *new_xyz, const int *prefix_in, int *prefix_out, int prefix_cap,
                                epnet_stream_t stream);
 /* same contract as epnet_three_nn (interpolate_gpu.cu:55-74); known_index = scene index of `known` (NULL: plain

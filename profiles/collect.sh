@@ -7,13 +7,14 @@
 #   4. per-op timings, the step with the FP ops, the batch sweep, BASELINE config 5, the training steps of configs 3 / 4
 # usage: bash profiles/collect.sh TAG [a|b|c]  -> gpurun_out/prof_TAG/*  (copy what should be judged into profiles/)
 #        (three parts, each within one gpurun call's time limit: a = 1-3, b = per-op / FP / sweep / config 5, c = training steps)
-set -e
+set -eu
 TAG=${1:-r02}
 PART=${2:-abc}
-OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
-mkdir -p $OUT
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+OUT="$ROOT/gpurun_out/prof_$TAG"
+mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
+cd "$ROOT"
 if [[ $PART == *a* ]]; then
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 echo "bench done"

@@ -1,8 +1,9 @@
-set -e
+set -eu
 cd /tmp && export TMPDIR=/tmp
-rm -rf $GRAFT_REPO_ROOT/gpurun_out/trace && mkdir -p $GRAFT_REPO_ROOT/gpurun_out/trace
-cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace -- python3 bench.py --cpu-scenes 0 --batch ${B:-256} --steps 4 --warmup 2 $EXTRA > gpurun_out/trace/bench.json
+ROOT="$(cd "$(dirname "$0")/../.." && pwd)"
+rm -rf "$ROOT/gpurun_out/trace" && mkdir -p "$ROOT/gpurun_out/trace"
+cd "$ROOT"
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace -- python3 bench.py --cpu-scenes 0 --batch ${B:-256} --steps 4 --warmup 2 ${EXTRA:-} > gpurun_out/trace/bench.json
 python3 - <<'PY'
 import csv, glob, collections
 f = glob.glob("gpurun_out/trace/**/*kernel_trace.csv", recursive=True)[0]

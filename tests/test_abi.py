@@ -90,3 +90,18 @@ def test_host_ops_match_oracle_and_fixture(hiplib, oracle):
     np.testing.assert_array_equal(pp.numpy(), fx["pooled_pts"])
     np.testing.assert_array_equal(pf.numpy(), fx["pooled_features"])
     np.testing.assert_array_equal(ef.numpy(), fx["pooled_empty_flag"])
+
+
+def test_scene_index_size_is_the_documented_layout(hiplib):
+    """epnet_scene_index_bytes (no GPU needed): per scene np float4 rows (np = the power of two >= max(n, 2048)), one box of 6
+    floats per 64 and per 256 rows and, beyond 16384 points, np floats of sampling scratch (include/epnet_ops.h) -- a caller
+    that sized the buffer by the formula of an older header would get EPNET_ENOMEM, so the formula is pinned here"""
+    def want(b, n):
+        if n < 1024 or n > 65536:
+            return 0
+        np_ = 2048
+        while np_ < n:
+            np_ *= 2
+        return b * (np_ * 16 + (np_ // 64 + np_ // 256) * 24 + (np_ * 4 if n > 16384 else 0))
+    for b, n in ((1, 1024), (3, 4096), (2, 16384), (2, 16385), (1, 40000), (4, 65536), (1, 1023), (1, 65537), (0, 4096)):
+        assert hiplib.epnet_scene_index_bytes(b, n) == (want(b, n) if b > 0 else 0), (b, n)

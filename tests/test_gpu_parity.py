@@ -1309,3 +1309,22 @@ def test_sample_and_gather_chains_through_the_centres():
     c1.mul_(1.0)                                                         # a write: the knowledge is void
     i2b, _ = p2u.sample_and_gather(c1, 1024, None)
     assert torch.equal(i2b, i2)
+
+
+def test_sample_pyramid_chains_explicitly_and_the_attribute_form_has_an_opt_out(monkeypatch):
+    """sample_pyramid hands the tie-free round counts from level to level itself (nothing attached to a tensor that escapes:
+    ADVICE r02); EPNET_SA_CHAIN=0 switches the attribute form of sample_and_gather off"""
+    from epnet_amd import pointnet2_utils as p2u
+    xyz = dev(rand_cloud(2, 16384, seed=5))
+    levels = p2u.sample_pyramid(xyz, [4096, 1024, 256, 64])
+    torch.cuda.synchronize()
+    for (idx, centres, _ev, _ix), m in zip(levels, (4096, 1024, 256, 64)):
+        assert not hasattr(centres, "_epnet_fps_prefix")
+    seq = torch.arange(1024, dtype=torch.int32, device=DEV).repeat(2, 1)
+    assert torch.equal(levels[1][0], seq) and torch.equal(levels[2][0], seq[:, :256]) and torch.equal(levels[3][0], seq[:, :64])
+    assert torch.equal(levels[1][0], p2u.furthest_point_sample(levels[0][1], 1024))      # what the rounds compute
+    monkeypatch.setenv("EPNET_SA_CHAIN", "0")
+    _, c1 = p2u.sample_and_gather(xyz, 4096, p2u.scene_index(xyz))
+    assert not hasattr(c1, "_epnet_fps_prefix")
+    i2, _ = p2u.sample_and_gather(c1, 1024, p2u.scene_index(c1))
+    assert torch.equal(i2, seq)                                                           # the rounds ran, same answer
