@@ -69,18 +69,42 @@ def decode_bbox_target(roi_box3d, pred_reg, loc_scope, loc_bin_size, num_head_bi
         cursor += 1
 
     # ---- heading (:126-152)
-    if ry_with_bin:
-        raise NotImplementedError("RY_WITH_BIN (bbox_transform.py:146-238) is off in every shipped config (lib/config.py:199,209)")
-    head = torch.argmax(pred_reg[:, cursor:cursor + num_head_bin], dim=1)
-    head_res = torch.gather(pred_reg[:, cursor + num_head_bin:cursor + num_head_bin * 2], dim=1, index=head.unsqueeze(dim=1)).squeeze(dim=1)
+    bin_logits = pred_reg[:, cursor:cursor + num_head_bin]
+    bin_res = pred_reg[:, cursor + num_head_bin:cursor + num_head_bin * 2]
     cursor += num_head_bin * 2
-    if get_ry_fine:      # a quarter turn split into bins around the ROI's own heading
-        per_bin = (np.pi / 2) / num_head_bin
-        ry = (head.float() * per_bin + per_bin / 2) + head_res * (per_bin / 2) - np.pi / 4
-    else:                # the full turn, wrapped into (-pi, pi]
-        per_bin = (2 * np.pi) / num_head_bin
-        ry = (head.float() * per_bin + head_res * (per_bin / 2)) % (2 * np.pi)
-        ry = torch.where(ry > np.pi, ry - 2 * np.pi, ry)   # `ry[ry > np.pi] -= 2 * np.pi` without the mask's host sync
+    if ry_with_bin:
+        # (:146-238) every bin proposes a heading; the bins fall on two sides (fine: left / right of the ROI's own heading,
+        # coarse: the first / second half turn); the answer is the probability-weighted mean over the likelier side -- a mean
+        # over both sides would average headings that point in opposite directions
+        prob = F.softmax(bin_logits, dim=1)
+        k = torch.arange(num_head_bin, device=pred_reg.device).float()
+        if get_ry_fine:
+            per_bin = (np.pi / 2) / num_head_bin
+            each = (k * per_bin + per_bin / 2) + bin_res * (per_bin / 2) - np.pi / 4
+            right = each >= 0
+        else:
+            per_bin = (2 * np.pi) / num_head_bin
+            each = (k * per_bin + bin_res * (per_bin / 2)) % (2 * np.pi)
+            right = each <= np.pi
+        zero = torch.zeros_like(prob)
+        p_right, p_left = torch.where(right, prob, zero), torch.where(right, zero, prob)
+        mass_right, mass_left = p_right.sum(dim=1, keepdim=True) + 1e-7, p_left.sum(dim=1, keepdim=True) + 1e-7
+        ry_right = (torch.where(right, each, zero) * (p_right / mass_right)).sum(dim=1)
+        ry_left = (torch.where(right, zero, each) * (p_left / mass_left)).sum(dim=1)
+        use_right = (mass_right >= mass_left).squeeze(1)
+        ry = ry_right * use_right.float() + ry_left * (~use_right).float()
+        if not get_ry_fine:
+            ry = torch.where(ry > np.pi, ry - 2 * np.pi, ry)
+    else:
+        head = torch.argmax(bin_logits, dim=1)
+        head_res = torch.gather(bin_res, dim=1, index=head.unsqueeze(dim=1)).squeeze(dim=1)
+        if get_ry_fine:      # a quarter turn split into bins around the ROI's own heading
+            per_bin = (np.pi / 2) / num_head_bin
+            ry = (head.float() * per_bin + per_bin / 2) + head_res * (per_bin / 2) - np.pi / 4
+        else:                # the full turn, wrapped into (-pi, pi]
+            per_bin = (2 * np.pi) / num_head_bin
+            ry = (head.float() * per_bin + head_res * (per_bin / 2)) % (2 * np.pi)
+            ry = torch.where(ry > np.pi, ry - 2 * np.pi, ry)   # `ry[ry > np.pi] -= 2 * np.pi` without the mask's host sync
 
     # ---- size (:243-248) and back to scene coordinates (:250-262)
     assert cursor + 3 == pred_reg.shape[1]

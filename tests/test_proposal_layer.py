@@ -204,3 +204,25 @@ def test_callers_resolve_under_the_reference_paths_and_read_its_cfg(monkeypatch)
         for k, v in saved.items():
             if v is not None:
                 sys.modules[k] = v
+
+
+def test_heading_as_weighted_mean_of_the_likelier_side_matches_the_reference():
+    """RY_WITH_BIN (lib/utils/bbox_transform.py:146-238; off in every shipped config, lib/config.py:199,209): the fixture is what
+    the reference's own decode_bbox_target returned with the switch on (tests/golden/make_golden_ry_bin.py), RPN and RCNN call
+    shapes, peaked and exactly flat bin distributions included"""
+    from epnet_amd import bbox_transform as bt, proposal_layer as pl
+    fx = golden("ry_with_bin.npz")
+    anchor = torch.from_numpy(pl.default_cfg().CLS_MEAN_SIZE[0])
+    got = bt.decode_bbox_target(T(fx["rpn_xyz"], "cpu"), T(fx["rpn_reg_f16"], "cpu").float(), anchor_size=anchor, loc_scope=3.0,
+                                loc_bin_size=0.5, num_head_bin=12, get_xz_fine=True, get_y_by_bin=False, get_ry_fine=False,
+                                bbox_avg_by_bin=False, ry_with_bin=True)
+    np.testing.assert_allclose(got.numpy(), fx["rpn_decoded"], rtol=1e-5, atol=1e-5)
+    got = bt.decode_bbox_target(T(fx["rcnn_rois"], "cpu"), T(fx["rcnn_reg_f16"], "cpu").float(), anchor_size=anchor, loc_scope=1.5,
+                                loc_bin_size=0.5, num_head_bin=9, get_xz_fine=True, get_y_by_bin=False, loc_y_scope=0.5,
+                                loc_y_bin_size=0.25, get_ry_fine=True, bbox_avg_by_bin=False, ry_with_bin=True)
+    np.testing.assert_allclose(got.numpy(), fx["rcnn_decoded"], rtol=1e-5, atol=1e-5)
+    # the switch changes the heading column only, and does change it
+    plain = bt.decode_bbox_target(T(fx["rcnn_rois"], "cpu"), T(fx["rcnn_reg_f16"], "cpu").float(), anchor_size=anchor, loc_scope=1.5,
+                                  loc_bin_size=0.5, num_head_bin=9, get_xz_fine=True, get_y_by_bin=False, loc_y_scope=0.5,
+                                  loc_y_bin_size=0.25, get_ry_fine=True, bbox_avg_by_bin=False, ry_with_bin=False)
+    assert torch.equal(plain[:, :6], got[:, :6]) and not torch.allclose(plain[:, 6], got[:, 6])
