@@ -735,16 +735,24 @@ __global__ __launch_bounds__(64 * kW) void fps_indexed_kernel(int n, int m, cons
 __device__ __forceinline__ unsigned rank16(int k) { return (bitrev_lg((unsigned)k & 1023u, 10) << 6) | ((unsigned)k >> 10); }
 __device__ __forceinline__ int unrank16(unsigned r) { return (int)(bitrev_lg(r >> 6, 10) + ((r & 63u) << 10)); }
 
-constexpr int kBigThreads = 1024;
-
-__global__ __launch_bounds__(kBigThreads) void fps_bigscene_kernel(int n, int np, int m, const float *__restrict__ xyz,
-                                                                  const float4 *__restrict__ sorted,
-                                                                  const float *__restrict__ boxes,
-                                                                  float *__restrict__ temp, float *__restrict__ tsort,
-                                                                  int *__restrict__ idxs, const int *__restrict__ skip) {
+// kW waves per scene, every lane owning 1024 / (64 kW) buckets. Measured (65536 -> 16384, one scene / 256 scenes):
+// 16 waves 0.88 / 1.18 us per round, 8 waves 1.11 / 1.47, 4 waves 1.50 / 1.97 -- the round is a chain of latencies through ONE
+// wave (winner read-back -> box tests -> row load -> update + bucket maximum -> the wave's arg-max -> LDS atomic -> barrier), and
+// a wave with four buckets per lane runs four box tests and up to four times the row updates back to back; the instructions
+// the sixteen waves issue in total are not what bounds it. 16 is the default (EPNET_FPS_BIG_WAVES = 4 | 8 keeps the others).
+template <int kW>
+__global__ __launch_bounds__(64 * kW) void fps_bigscene_kernel(int n, int np, int m, const float *__restrict__ xyz,
+                                                               const float4 *__restrict__ sorted,
+                                                               const float *__restrict__ boxes,
+                                                               float *__restrict__ temp, float *__restrict__ tsort,
+                                                               int *__restrict__ idxs, const int *__restrict__ skip) {
     if (skip && skip[blockIdx.x] >= m) return;
+    constexpr int kT = 64 * kW;
+    constexpr int kBPL = 1024 / kT;   // buckets per lane (np <= 65536: at most 1024 buckets)
+    constexpr int kLgW = kW == 16 ? 4 : (kW == 8 ? 3 : 2);
+    static_assert(kW == 4 || kW == 8 || kW == 16, "bucket dealing assumes 4, 8 or 16 waves");
     __shared__ unsigned long long s_key[3];
-    __shared__ float4 s_rec[2][16];
+    __shared__ float4 s_rec[2][kW];
     __shared__ int s_idx[kIdxBufP];
     const int q = threadIdx.x;
     const int lane = q & 63, wave = q >> 6;
@@ -756,31 +764,39 @@ __global__ __launch_bounds__(kBigThreads) void fps_bigscene_kernel(int n, int np
     tsort += (size_t)blockIdx.x * np;
     idxs += (size_t)blockIdx.x * m;
     const int kNeg1 = __float_as_int(-1.f);
-    constexpr int kWaves = kBigThreads / 64;
-    // Bucket j of this wave is bucket (j * 16 + wave) of the scene: consecutive buckets of the sorted order are spatial
-    // neighbours, and a new sample touches a handful of neighbouring buckets -- dealt round-robin they land on different
-    // waves, which re-read them side by side instead of one wave working through them one L2 round trip after the other
-    // (65536 -> 16384 samples: 2.26 -> ... us per round with the distances in sorted order and two buckets per trip)
-    auto bid = [&](int j) { return (j << 4) | wave; };
-    static_assert(kWaves == 16, "bucket dealing assumes 16 waves");
+    // Bucket e (= 0 .. 64 kBPL - 1) of this wave is bucket (e * kW + wave) of the scene; lane e % 64 keeps its summary in slot
+    // e / 64. Consecutive buckets of the sorted order are spatial neighbours, and a new sample touches a handful of neighbouring
+    // buckets -- dealt round-robin they land on different waves, which re-read them side by side instead of one wave working
+    // through them one L2 round trip after the other
+    auto bid = [&](int e) { return (e << kLgW) | wave; };
 
-    const bool own = bid(lane) < nb;
-    float lox = 0.f, hix = 0.f, loy = 0.f, hiy = 0.f, loz = 0.f, hiz = 0.f;
-    if (own) {
-        const float *bx = boxes + bid(lane) * 6;
-        lox = bx[0]; hix = bx[1]; loy = bx[2]; hiy = bx[3]; loz = bx[4]; hiz = bx[5];
+    float lox[kBPL], hix[kBPL], loy[kBPL], hiy[kBPL], loz[kBPL], hiz[kBPL];
+    bool own[kBPL];
+    int bm[kBPL];               // maximum running distance of my bucket (bits); -1: nothing real in it
+    unsigned brank[kBPL];       // reference rank of the point holding it
+    float bxx[kBPL], byy[kBPL], bzz[kBPL];
+#pragma unroll
+    for (int s_ = 0; s_ < kBPL; ++s_) {
+        const int b_ = bid(s_ * 64 + lane);
+        own[s_] = b_ < nb;
+        lox[s_] = hix[s_] = loy[s_] = hiy[s_] = loz[s_] = hiz[s_] = 0.f;
+        if (own[s_]) {
+            const float *bx = boxes + b_ * 6;
+            lox[s_] = bx[0]; hix[s_] = bx[1]; loy[s_] = bx[2]; hiy[s_] = bx[3]; loz[s_] = bx[4]; hiz[s_] = bx[5];
+        }
+        bm[s_] = kNeg1;
+        brank[s_] = 0xFFFFu;
+        bxx[s_] = byy[s_] = bzz[s_] = 0.f;
     }
-    int bm = kNeg1;             // maximum running distance of my bucket (bits); -1: nothing real in it
-    unsigned brank = 0xFFFFu;   // reference rank of the point holding it
-    float bxx = 0.f, byy = 0.f, bzz = 0.f;
+    const int nmine = 64 * kBPL;   // bucket slots of this wave
 
     // The caller's running distances are indexed by ORIGINAL point number: a bucket's 64 values would be 64 cache lines.
     // The rounds keep them in SORTED order instead, in the sampling scratch at the tail of the scene index (one 256-byte
     // row per bucket, fetched beside the bucket's 1 KB row of the index); gathered on the way in, scattered back on the
     // way out. (The original index of a point rides in the .w of its index row: nothing per point is kept in registers --
-    // a 16-wave workgroup that holds few registers leaves the rest of the CU to the bandwidth-bound kernels beside it.)
-    for (int j = 0; j < 64; ++j) {
-        const int pos = (bid(j) << 6) + lane;
+    // a workgroup that holds few registers leaves the rest of the CU to the bandwidth-bound kernels beside it.)
+    for (int e = 0; e < nmine; ++e) {
+        const int pos = (bid(e) << 6) + lane;
         if (pos < n) tsort[pos] = temp[__float_as_int(sorted[pos].w)];
     }
 
@@ -788,16 +804,16 @@ __global__ __launch_bounds__(kBigThreads) void fps_bigscene_kernel(int n, int np
         float4 p;
         int t;
     };
-    auto load_row = [&](int j) {
+    auto load_row = [&](int e) {
         Row r;
-        const int pos = (bid(j) << 6) + lane;
+        const int pos = (bid(e) << 6) + lane;
         r.p = sorted[pos];
         r.t = pos < n ? __float_as_int(tsort[pos]) : kNeg1;
         return r;
     };
-    // (re)computes the summary of bucket j of this wave from its row; with `update`, first lowers its distances by the sample c
-    auto finish = [&](int j, Row r, bool update, float cx, float cy, float cz) {
-        const int pos = (bid(j) << 6) + lane;
+    // (re)computes the summary of bucket e of this wave from its row; with `update`, first lowers its distances by the sample c
+    auto finish = [&](int e, Row r, bool update, float cx, float cy, float cz) {
+        const int pos = (bid(e) << 6) + lane;
         const int k = __float_as_int(r.p.w);   // original index (padding rows: -1, never `real`)
         const bool real = pos < n;
         int t = r.t;
@@ -821,15 +837,19 @@ __global__ __launch_bounds__(kBigThreads) void fps_bigscene_kernel(int n, int np
         const float wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.p.x), wl));
         const float wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.p.y), wl));
         const float wz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.p.z), wl));
-        if (lane == j) {
-            bm = mx;
-            brank = rwin;
-            bxx = wx; byy = wy; bzz = wz;
-        }
+        const bool mine = lane == (e & 63);
+        const int slot = e >> 6;   // wave-uniform
+#pragma unroll
+        for (int s_ = 0; s_ < kBPL; ++s_)
+            if (mine && s_ == slot) {
+                bm[s_] = mx;
+                brank[s_] = rwin;
+                bxx[s_] = wx; byy[s_] = wy; bzz[s_] = wz;
+            }
     };
 
-    for (int j = 0; j < 64; ++j)
-        if (bid(j) < nb) finish(j, load_row(j), false, 0.f, 0.f, 0.f);  // wave-uniform
+    for (int e = 0; e < nmine; ++e)
+        if (bid(e) < nb) finish(e, load_row(e), false, 0.f, 0.f, 0.f);  // wave-uniform
     if (q < 3) s_key[q] = 0ull;
     if (q == 0) s_idx[0] = 0;  // rank 0 == point 0
     float cx = xyz[0], cy = xyz[1], cz = xyz[2];
@@ -839,45 +859,72 @@ __global__ __launch_bounds__(kBigThreads) void fps_bigscene_kernel(int n, int np
     bool stale = true;
     int wbest = kNeg1;
     bool publisher = false;
+    unsigned pub_rank = 0xFFFFu;
+    float pub_x = 0.f, pub_y = 0.f, pub_z = 0.f;
     int kb = 1;
     for (int it = 1; it < m; ++it) {
         // A. which buckets can change?  (same fp32 expression as the point distance: exact)
-        const float px = __builtin_amdgcn_fmed3f(cx, lox, hix), py = __builtin_amdgcn_fmed3f(cy, loy, hiy),
-                    pz = __builtin_amdgcn_fmed3f(cz, loz, hiz);
-        const float bdx = px - cx, bdy = py - cy, bdz = pz - cz;
-        const float L = bdx * bdx + bdy * bdy + bdz * bdz;
-        unsigned long long active = __ballot(own && __float_as_int(L) < bm);
-        stale = stale || active != 0ull;
+        unsigned long long active[kBPL];
+        bool any = false;
+#pragma unroll
+        for (int s_ = 0; s_ < kBPL; ++s_) {
+            const float px = __builtin_amdgcn_fmed3f(cx, lox[s_], hix[s_]), py = __builtin_amdgcn_fmed3f(cy, loy[s_], hiy[s_]),
+                        pz = __builtin_amdgcn_fmed3f(cz, loz[s_], hiz[s_]);
+            const float bdx = px - cx, bdy = py - cy, bdz = pz - cz;
+            const float L = bdx * bdx + bdy * bdy + bdz * bdz;
+            active[s_] = __ballot(own[s_] && __float_as_int(L) < bm[s_]);
+            any = any || active[s_] != 0ull;
+        }
+        stale = stale || any;
         // B. re-read and update them, two rows per trip to L2
-        while (active) {
-            const int j0 = (int)__builtin_ctzll(active);
-            active &= active - 1ull;
-            const bool two = active != 0ull;
-            const int j1 = two ? (int)__builtin_ctzll(active) : j0;
-            active &= active - 1ull;  // (no-op on 0)
-            const Row r0 = load_row(j0);
-            Row r1 = r0;
-            if (two) r1 = load_row(j1);
-            finish(j0, r0, true, cx, cy, cz);
-            if (two) finish(j1, r1, true, cx, cy, cz);
+#pragma unroll
+        for (int s_ = 0; s_ < kBPL; ++s_) {
+            unsigned long long act = active[s_];
+            while (act) {
+                const int e0 = s_ * 64 + (int)__builtin_ctzll(act);
+                act &= act - 1ull;
+                const bool two = act != 0ull;
+                const int e1 = two ? s_ * 64 + (int)__builtin_ctzll(act) : e0;
+                act &= act - 1ull;  // (no-op on 0)
+                const Row r0 = load_row(e0);
+                Row r1 = r0;
+                if (two) r1 = load_row(e1);
+                finish(e0, r0, true, cx, cy, cz);
+                if (two) finish(e1, r1, true, cx, cy, cz);
+            }
         }
         // C. this wave's best bucket (ties by rank)
         if (stale) {
             stale = false;
-            wbest = wave_max_all(bm);
-            unsigned long long cand = __ballot(bm == wbest && bm != kNeg1);
+            int lmax = bm[0];
+#pragma unroll
+            for (int s_ = 1; s_ < kBPL; ++s_) lmax = max(lmax, bm[s_]);
+            wbest = wave_max_all(lmax);
+            // my best candidate among the slots that hold the wave's maximum: the smallest rank
+            unsigned lrank = 0xFFFFFFFFu;
+            float lx = 0.f, ly = 0.f, lz = 0.f;
+#pragma unroll
+            for (int s_ = 0; s_ < kBPL; ++s_) {
+                const bool take = bm[s_] == wbest && bm[s_] != kNeg1 && brank[s_] < lrank;
+                lrank = take ? brank[s_] : lrank;
+                lx = take ? bxx[s_] : lx;
+                ly = take ? byy[s_] : ly;
+                lz = take ? bzz[s_] : lz;
+            }
+            unsigned long long cand = __ballot(lrank != 0xFFFFFFFFu);
             if (cand & (cand - 1ull)) {
-                // (the cross-lane minimum must not sit behind a short-circuit '&&': it needs every lane)
-                const unsigned rmin = wave_min_all(bm == wbest ? brank : 0xFFFFFFFFu);
-                cand = __ballot(bm == wbest && brank == rmin);
+                const unsigned rmin = wave_min_all(lrank);   // (every lane takes part: no short-circuit in front of it)
+                cand = __ballot(lrank == rmin);
             }
             publisher = cand != 0ull && lane == (int)__builtin_ctzll(cand);
+            pub_rank = lrank;
+            pub_x = lx; pub_y = ly; pub_z = lz;
         }
         const int buf = it & 1;
         if (publisher) {
-            s_rec[buf][wave] = make_float4(bxx, byy, bzz, 0.f);
+            s_rec[buf][wave] = make_float4(pub_x, pub_y, pub_z, 0.f);
             const unsigned long long key =
-                ((unsigned long long)(unsigned)wbest << 32) | (unsigned long long)(((0xFFFFu - brank) << 4) | (unsigned)wave);
+                ((unsigned long long)(unsigned)wbest << 32) | (unsigned long long)(((0xFFFFu - pub_rank) << 4) | (unsigned)wave);
             __hip_atomic_fetch_max(&s_key[kb], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         __syncthreads();
@@ -904,8 +951,8 @@ __global__ __launch_bounds__(kBigThreads) void fps_bigscene_kernel(int n, int np
     }
     // the running distances back into the caller's order (a wave reads only what it wrote itself)
     __builtin_amdgcn_s_setprio(0);
-    for (int j = 0; j < 64; ++j) {
-        const int pos = (bid(j) << 6) + lane;
+    for (int e = 0; e < nmine; ++e) {
+        const int pos = (bid(e) << 6) + lane;
         if (pos < n) temp[__float_as_int(sorted[pos].w)] = tsort[pos];
     }
 }
@@ -1193,8 +1240,15 @@ static int fps_over_index(int b, int n, int m, const float *xyz, void *index, si
                 if (rc) return rc;
             }
             const int np = scene_index_np(n);
-            hipLaunchKernelGGL(pruned::fps_bigscene_kernel, grid, dim3(pruned::kBigThreads), 0, s, n, np, m, xyz, sorted,
-                               (const float *)(sorted + (size_t)b * np), temp, scene_index_sampling_scratch(b, n, index), idx, skip);
+            const float *bucket_boxes = (const float *)(sorted + (size_t)b * np);
+            float *tsort = scene_index_sampling_scratch(b, n, index);
+            const int big_waves = getenv("EPNET_FPS_BIG_WAVES") ? atoi(getenv("EPNET_FPS_BIG_WAVES")) : 16;
+            if (big_waves == 4)
+                hipLaunchKernelGGL(pruned::fps_bigscene_kernel<4>, grid, dim3(256), 0, s, n, np, m, xyz, sorted, bucket_boxes, temp, tsort, idx, skip);
+            else if (big_waves == 8)
+                hipLaunchKernelGGL(pruned::fps_bigscene_kernel<8>, grid, dim3(512), 0, s, n, np, m, xyz, sorted, bucket_boxes, temp, tsort, idx, skip);
+            else
+                hipLaunchKernelGGL(pruned::fps_bigscene_kernel<16>, grid, dim3(1024), 0, s, n, np, m, xyz, sorted, bucket_boxes, temp, tsort, idx, skip);
         } else {
             const int wide = getenv("EPNET_FPS_WIDE") ? atoi(getenv("EPNET_FPS_WIDE")) : 0;
             // the centres can come out of the sampling kernel itself (kCtr: the round's winner is in registers anyway) or from a

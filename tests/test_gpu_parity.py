@@ -133,6 +133,9 @@ def test_fps_golden_fixtures():
     ({"EPNET_FPS_CTR": "1"}, 4096, 1024, "kitti"),
     ({"EPNET_FPS_CTR": "1"}, 2048, 512, "kitti"),
     ({"EPNET_FPS_CTR": "1", "EPNET_FPS_WIDE": "1"}, 16384, 1024, "dup"),
+    ({"EPNET_FPS_BIG_WAVES": "4"}, 40000, 900, "kitti"),    # workgroup shapes of the big-scene kernel: 4 / 8 waves, 4 / 2 buckets per lane
+    ({"EPNET_FPS_BIG_WAVES": "8"}, 65536, 700, "dup"),
+    ({"EPNET_FPS_BIG_WAVES": "4"}, 20000, 1200, "dup"),
 ])
 def test_fps_tuning_variants_match_oracle(oracle, monkeypatch, env, n, m, kind):
     """every kernel variant an EPNET_FPS_* variable selects (read per call) gives the oracle's indices, running
