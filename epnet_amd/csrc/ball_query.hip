@@ -506,8 +506,9 @@ __global__ __launch_bounds__(kQThreads) void bq_query_kernel(int np, int m, BqSc
     __shared__ int s_quads[kQThreads / 64][64];
     __shared__ int s_hits[kQThreads / 64][K][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int bs = blockIdx.y;
-    int ci = blockIdx.x * (kQThreads / 64) + wave;
+    int wg_x, bs;
+    xcd_scene_map(wg_x, bs);   // a scene's index passes through one XCD's L2
+    int ci = wg_x * (kQThreads / 64) + wave;
     if (ci >= m) return;  // wave-uniform; no block-level barrier below
     sorted += (size_t)bs * np;
     boxes += (size_t)bs * (np / 64) * 6;
@@ -566,8 +567,9 @@ __global__ __launch_bounds__(kQThreads) void bq_query2_kernel(int np, int m, BqS
     __shared__ int s_quads[kQThreads / 64][2][64];
     __shared__ int s_hits[kQThreads / 64][2][K][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int bs = blockIdx.y;
-    const int ci0 = (blockIdx.x * (kQThreads / 64) + wave) * 2;
+    int wg_x, bs;
+    xcd_scene_map(wg_x, bs);   // a scene's index passes through one XCD's L2
+    const int ci0 = (wg_x * (kQThreads / 64) + wave) * 2;
     if (ci0 >= m) return;  // wave-uniform; no block-level barrier below
     const bool two = ci0 + 1 < m;
     sorted += (size_t)bs * np;

@@ -36,6 +36,45 @@ __device__ __forceinline__ void store_stream(float *dst, float x, float y, float
     __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(dst));
 }
 
+// XCD-aware relabelling of a (gridDim.x workgroups per scene, gridDim.y scenes) launch. Workgroups are dealt round-robin over the 8
+// XCDs by their linear id, and every XCD has an L2 of its own: with the plain (blockIdx.x, blockIdx.y) mapping the eight
+// neighbours in launch order -- which all work on the SAME scene -- sit on eight different XCDs, and each of them pulls its own
+// copy of that scene's tables (scene index, coordinates, feature rows) through the fabric: 8x the compulsory fetch traffic on
+// whatever the workgroups of a scene share (level-1 ball query: 2.9 MB moved per scene for 1.1 MB of index + output).
+// Here XCD k takes the k-th eighth of the linear ids in order, i.e. whole scenes one after the other: a scene's tables pass
+// through ONE L2. A bijection of the ids; placement is a matter of speed only (nothing assumes where a workgroup runs).
+// EPNET_XCD_MAP=0 in the environment of the build (-DEPNET_NO_XCD_MAP) keeps the plain mapping for measurements.
+__device__ __forceinline__ void xcd_scene_map(int &wg_x, int &bs) {
+#ifdef EPNET_NO_XCD_MAP
+    wg_x = (int)blockIdx.x;
+    bs = (int)blockIdx.y;
+#else
+    const int gx = (int)gridDim.x, nwg = gx * (int)gridDim.y, orig = (int)blockIdx.y * gx + (int)blockIdx.x;
+    const int xcd = orig & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int wgid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3);
+    bs = wgid / gx;
+    wg_x = wgid - bs * gx;
+#endif
+}
+
+// the same for a (gridDim.x, gridDim.y) grid of workgroups per scene and gridDim.z scenes
+__device__ __forceinline__ void xcd_scene_map3(int &wg_x, int &wg_y, int &bs) {
+#ifdef EPNET_NO_XCD_MAP
+    wg_x = (int)blockIdx.x;
+    wg_y = (int)blockIdx.y;
+    bs = (int)blockIdx.z;
+#else
+    const int gx = (int)gridDim.x, per_scene = gx * (int)gridDim.y, nwg = per_scene * (int)gridDim.z;
+    const int orig = ((int)blockIdx.z * (int)gridDim.y + (int)blockIdx.y) * gx + (int)blockIdx.x;
+    const int xcd = orig & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int wgid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3);
+    bs = wgid / per_scene;
+    const int in_scene = wgid - bs * per_scene;
+    wg_y = in_scene / gx;
+    wg_x = in_scene - wg_y * gx;
+#endif
+}
+
 // sum over the 64 lanes of a wave, result in every lane
 __device__ __forceinline__ float wave_sum_f32(float v) {
 #pragma unroll

@@ -32,9 +32,10 @@ __global__ __launch_bounds__(kGThreads) void gather_rows_vec4_kernel(int c, int 
                                                                      const float *__restrict__ points,
                                                                      const int *__restrict__ idx,
                                                                      float *__restrict__ out) {
-    const int bs = blockIdx.z;
-    const int c0 = blockIdx.y * kGChan;
-    const int q4 = blockIdx.x * kGThreads + threadIdx.x;  // group of 4 positions
+    int wg_x, wg_y, bs;
+    xcd_scene_map3(wg_x, wg_y, bs);   // a scene's rows and indices pass through one XCD's L2
+    const int c0 = wg_y * kGChan;
+    const int q4 = wg_x * kGThreads + threadIdx.x;  // group of 4 positions
     if (q4 * 4 >= p) return;
     const int4 id = *reinterpret_cast<const int4 *>(idx + (size_t)bs * p + (size_t)q4 * 4);
     const int cend = min(c, c0 + kGChan);
@@ -57,9 +58,10 @@ __global__ __launch_bounds__(kGThreads) void gather_rows_scalar_kernel(int c, in
                                                                        const float *__restrict__ points,
                                                                        const int *__restrict__ idx,
                                                                        float *__restrict__ out) {
-    const int bs = blockIdx.z;
-    const int c0 = blockIdx.y * kGChan;
-    const int q = blockIdx.x * kGThreads + threadIdx.x;
+    int wg_x, wg_y, bs;
+    xcd_scene_map3(wg_x, wg_y, bs);   // a scene's rows and indices pass through one XCD's L2
+    const int c0 = wg_y * kGChan;
+    const int q = wg_x * kGThreads + threadIdx.x;
     if (q >= p) return;
     const int id = idx[(size_t)bs * p + q];
     const int cend = min(c, c0 + kGChan);
@@ -136,8 +138,9 @@ __global__ __launch_bounds__(kGLdsThreads) void gather_rows_lds_kernel(int c, in
                                                                     const int *__restrict__ idx,
                                                                     float *__restrict__ out) {
     extern __shared__ float s_rows[];
-    const int bs = blockIdx.z;
-    const int c0 = blockIdx.y * rows;
+    int wg_x, wg_y, bs;
+    xcd_scene_map3(wg_x, wg_y, bs);   // a scene's rows and indices pass through one XCD's L2
+    const int c0 = wg_y * rows;
     const int nr = min(rows, c - c0);
     const float *src = points + ((size_t)bs * c + c0) * n;
     const int total = nr * n;
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(kGLdsThreads) void gather_rows_lds_kernel(int c, in
         for (int e = threadIdx.x; e < total; e += kGLdsThreads) s_rows[e] = src[e];
     }
     __syncthreads();
-    const int q_begin = blockIdx.x * tile, q_end = min(p, q_begin + tile);
+    const int q_begin = wg_x * tile, q_end = min(p, q_begin + tile);
     const int *ix = idx + (size_t)bs * p;
     float *dst_base = out + (size_t)bs * ostride + (size_t)c0 * p;
     for (int q = q_begin + threadIdx.x * 4; q < q_end; q += kGLdsThreads * 4) {
@@ -188,8 +191,9 @@ __global__ __launch_bounds__(kGLdsThreads) void gather_rows_lds2_kernel(int c, i
                                                                         float *__restrict__ out0, int p1, size_t ostride1,
                                                                         const int *__restrict__ idx1, float *__restrict__ out1) {
     extern __shared__ float s_rows[];
-    const int bs = blockIdx.y;
-    const int c0 = blockIdx.x * rows;
+    int wg_x, bs;
+    xcd_scene_map(wg_x, bs);   // the index tensors of a scene are read by all its row chunks: through one XCD's L2
+    const int c0 = wg_x * rows;
     const int nr = min(rows, c - c0);
     const float *src = points + ((size_t)bs * c + c0) * n;
     const int total = nr * n;
@@ -272,9 +276,10 @@ __global__ __launch_bounds__(kGThreads) void group_xyz_centred_kernel(int n, int
                                                                       const float *__restrict__ xyz,
                                                                       const float *__restrict__ new_xyz,
                                                                       const int *__restrict__ idx, float *__restrict__ out) {
-    const int bs = blockIdx.y;
+    int wg_x, bs;
+    xcd_scene_map(wg_x, bs);   // a scene's coordinates pass through one XCD's L2
     const int p = npoints * nsample;
-    const int q = blockIdx.x * kGThreads + threadIdx.x;
+    const int q = wg_x * kGThreads + threadIdx.x;
     if (q >= p) return;
     const int id = idx[(size_t)bs * p + q];
     const int ci = q / nsample;
@@ -292,9 +297,10 @@ __global__ __launch_bounds__(kGThreads) void group_xyz_centred_vec4_kernel(int n
                                                                            const float *__restrict__ new_xyz,
                                                                            const int *__restrict__ idx,
                                                                            float *__restrict__ out) {
-    const int bs = blockIdx.y;
+    int wg_x, bs;
+    xcd_scene_map(wg_x, bs);   // a scene's coordinates pass through one XCD's L2
     const int p = npoints * nsample;
-    const int q = (blockIdx.x * kGThreads + threadIdx.x) * 4;
+    const int q = (wg_x * kGThreads + threadIdx.x) * 4;
     if (q >= p) return;
     const int4 id = *reinterpret_cast<const int4 *>(idx + (size_t)bs * p + q);
     const float *base = xyz + (size_t)bs * n * 3;
@@ -489,7 +495,9 @@ __global__ __launch_bounds__(kPmThreads) void gather_rows_pm_kernel(int c, int n
                                                                     const float *__restrict__ points_t,
                                                                     const int *__restrict__ idx, float *__restrict__ out) {
     extern __shared__ float s_tile[];  // [c][kPmTile]
-    const int bs = blockIdx.y, q0 = blockIdx.x * kPmTile;
+    int wg_x, bs;
+    xcd_scene_map(wg_x, bs);   // an XCD gathers from ONE scene's point-major copy at a time (a quarter of it fits its L2) instead of from all the chunk's
+    const int q0 = wg_x * kPmTile;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int lanes_per_row = c >> 2, rows_per_pass = kPmThreads / lanes_per_row;
     points_t += (size_t)bs * n * c;

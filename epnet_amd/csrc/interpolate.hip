@@ -271,8 +271,9 @@ __global__ __launch_bounds__(kNnTileThreads) void three_nn_tile_kernel(int n, in
                                                                        float *__restrict__ dist2, int *__restrict__ idx) {
     extern __shared__ float s_boxes[];                  // the known buckets' boxes, shared by the 4 waves
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int bs = blockIdx.y;
-    const int ub = blockIdx.x * (kNnTileThreads / 64) + wave;
+    int wg_x, bs;
+    xcd_scene_map(wg_x, bs);   // a scene's two indices pass through one XCD's L2
+    const int ub = wg_x * (kNnTileThreads / 64) + wave;
     sorted_u += (size_t)bs * npu;
     boxes_u += (size_t)bs * (npu >> 6) * 6;
     sorted_k += (size_t)bs * npk;
@@ -479,9 +480,10 @@ __global__ __launch_bounds__(kTiThreads) void three_interpolate_kernel(int c, in
                                                                        const int *__restrict__ idx,
                                                                        const float *__restrict__ weight,
                                                                        float *__restrict__ out) {
-    const int bs = blockIdx.z;
-    const int c0 = blockIdx.y * kTiChan;
-    const int i0 = (blockIdx.x * kTiThreads + threadIdx.x) * 4;
+    int wg_x, wg_y, bs;
+    xcd_scene_map3(wg_x, wg_y, bs);   // a scene's idx / weight rows are read by every channel group: through one XCD's L2
+    const int c0 = wg_y * kTiChan;
+    const int i0 = (wg_x * kTiThreads + threadIdx.x) * 4;
     if (i0 >= n) return;
     const int cnt = min(4, n - i0);
     int ix[4][3];
@@ -519,8 +521,9 @@ __global__ __launch_bounds__(kTiThreads) void three_interpolate_lds_kernel(int c
                                                                            const float *__restrict__ weight,
                                                                            float *__restrict__ out) {
     extern __shared__ float s_rows[];
-    const int bs = blockIdx.z;
-    const int c0 = blockIdx.y * rows;
+    int wg_x, wg_y, bs;
+    xcd_scene_map3(wg_x, wg_y, bs);   // a scene's idx / weight rows are read by every row chunk: through one XCD's L2
+    const int c0 = wg_y * rows;
     const int nr = min(rows, c - c0);
     const float *src = points + ((size_t)bs * c + c0) * m;
     const int total = nr * m;
@@ -532,7 +535,7 @@ __global__ __launch_bounds__(kTiThreads) void three_interpolate_lds_kernel(int c
         for (int e = threadIdx.x; e < total; e += kTiThreads) s_rows[e] = src[e];
     }
     __syncthreads();
-    const int i_begin = blockIdx.x * tile, i_end = min(n, i_begin + tile);
+    const int i_begin = wg_x * tile, i_end = min(n, i_begin + tile);
     float *dst_base = out + ((size_t)bs * c + c0) * n;
     for (int i0 = i_begin + threadIdx.x * 4; i0 < i_end; i0 += kTiThreads * 4) {
         int ix[4][3];
@@ -569,8 +572,9 @@ __global__ __launch_bounds__(kTiThreads) void three_interpolate_lds4_kernel(int 
                                                                             const float *__restrict__ weight,
                                                                             float *__restrict__ out) {
     extern __shared__ float4 s_quad[];  // [rows / 4][m] float4 = the four channels of one known point
-    const int bs = blockIdx.z;
-    const int c0 = blockIdx.y * rows;
+    int wg_x, wg_y, bs;
+    xcd_scene_map3(wg_x, wg_y, bs);   // a scene's idx / weight rows are read by every row chunk: through one XCD's L2
+    const int c0 = wg_y * rows;
     const int nr = min(rows, c - c0);  // multiple of 4
     const int groups = nr >> 2, m4 = m >> 2;
     const float *src = points + ((size_t)bs * c + c0) * m;
@@ -585,7 +589,7 @@ __global__ __launch_bounds__(kTiThreads) void three_interpolate_lds4_kernel(int 
         dst[3] = make_float4(a.w, b4.w, cc.w, d.w);
     }
     __syncthreads();
-    const int i_begin = blockIdx.x * tile, i_end = min(n, i_begin + tile);
+    const int i_begin = wg_x * tile, i_end = min(n, i_begin + tile);
     float *dst_base = out + ((size_t)bs * c + c0) * n;
     for (int i0 = i_begin + threadIdx.x * U; i0 < i_end; i0 += kTiThreads * U) {
         int ix[U][3];

@@ -310,8 +310,10 @@ def ball_query_indexed_wrapper(b, n, m, radius, nsample, new_xyz, xyz, index, id
     return 1
 
 @writes("out")
-def group_concat_wrapper(b, c, n, npoints, nsample, xyz, new_xyz, features, idx, out, use_xyz):
-    """out (B, 3+C | C, M, ns) = [grouped xyz - centre ; grouped features]; features may be None when c == 0"""
+def group_concat_wrapper(b, c, n, npoints, nsample, xyz, new_xyz, features, idx, out, use_xyz, workspace=None):
+    """out (B, 3+C | C, M, ns) = [grouped xyz - centre ; grouped features]; features may be None when c == 0.
+    workspace (optional): a uint8 tensor of group_concat_workspace_bytes(...) bytes the caller keeps (rows too long for on-chip
+    staging go through a point-major copy of the features there); None: allocated per call"""
     px = dev_ptr(xyz, "xyz", _F) if use_xyz else None
     pn = dev_ptr(new_xyz, "new_xyz", _F) if use_xyz else None
     pf = dev_ptr(features, "features", _F) if c else None
@@ -325,12 +327,19 @@ def group_concat_wrapper(b, c, n, npoints, nsample, xyz, new_xyz, features, idx,
     ws_bytes = l.epnet_group_concat_workspace_bytes(b, c, n, npoints, nsample) if c else 0
     with on_device_of(idx) as s:
         if ws_bytes:   # rows too long for on-chip staging: scratch for a point-major copy of the features
-            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=idx.device)
+            ws = workspace if workspace is not None else torch.empty((ws_bytes,), dtype=torch.uint8, device=idx.device)
+            if ws.dtype != torch.uint8 or ws.numel() < ws_bytes or ws.device != idx.device or not ws.is_contiguous():
+                raise RuntimeError("group_concat workspace: a contiguous uint8 tensor of >= %d bytes on the tensors' device" % ws_bytes)
             _lib.check(l.epnet_group_concat_ws(b, c, n, npoints, nsample, px, pn, pf, pi, po, int(bool(use_xyz)), ws.data_ptr(),
-                                               ws_bytes, s), "group_concat")
+                                               ws.numel(), s), "group_concat")
         else:
             _lib.check(l.epnet_group_concat(b, c, n, npoints, nsample, px, pn, pf, pi, po, int(bool(use_xyz)), s), "group_concat")
     return 1
+
+
+def group_concat_workspace_bytes(b, c, n, npoints, nsample):
+    """scratch bytes group_concat_wrapper can use for this shape (0: none helps)"""
+    return int(_lib.lib().epnet_group_concat_workspace_bytes(b, c, n, npoints, nsample)) if c else 0
 
 
 @writes("outs")

@@ -179,6 +179,8 @@ class SAStack:
                                               if lvl in self.s_query_levels else [])
                 if fused:
                     S["grouped"] = torch.empty((batch, 3 + c, m, ns), dtype=f32, device=dev)
+                    ws_bytes = ext.group_concat_workspace_bytes(batch, c, cur, m, ns)   # (long feature rows: a point-major copy)
+                    S["workspace"] = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes else None
                 else:
                     S["grouped_xyz"] = torch.empty((batch, 3, m, ns), dtype=f32, device=dev)
                     S["grouped_feat"] = torch.empty((batch, c, m, ns), dtype=f32, device=dev) if c else None
@@ -311,7 +313,7 @@ class SAStack:
         b, n, m = self.batch, L["n"], L["m"]
         if self.fused:   # pointnet2_utils.py:249-257 in one call
             ext.group_concat_wrapper(b, L["c"], n, m, S["ns"], cur_xyz, L["sets"][parity]["new_xyz"], L["features"],
-                                     self._idx(S, parity), S["grouped"], True)
+                                     self._idx(S, parity), S["grouped"], True, S.get("workspace"))
         else:
             ext.group_points_wrapper(b, 3, n, m, S["ns"], L["xyz_t"], self._idx(S, parity), S["grouped_xyz"])
             if L["c"]:

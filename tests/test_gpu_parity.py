@@ -1169,7 +1169,8 @@ def test_config5_stack_against_the_oracle(oracle):
     assert bench.verify_scene(stack, stack.inputs[0], 1) == []
 
 
-@pytest.mark.parametrize("b,c,n,m,ns", [(2, 64, 65536, 2048, 64), (1, 16, 40000, 4000, 20), (2, 128, 20000, 700, 32), (1, 20, 17000, 2001, 12)])
+@pytest.mark.parametrize("b,c,n,m,ns", [(2, 64, 65536, 2048, 64), (1, 16, 40000, 4000, 20), (2, 128, 20000, 700, 32), (1, 20, 17000, 2001, 12),
+                                        (1, 64, 65536, 16384, 64), (1, 24, 30000, 3000, 128)])
 def test_group_concat_long_rows_through_point_major_scratch(oracle, b, c, n, m, ns):
     """feature rows beyond LDS (n > 16384): epnet_group_concat_ws gathers from a point-major copy of the features; identical
     to the plain entry point and to the oracle's grouping"""
@@ -1193,6 +1194,11 @@ def test_group_concat_long_rows_through_point_major_scratch(oracle, b, c, n, m, 
     only = torch.full((b, c, m, ns), float("nan"), device=DEV)
     ext.group_concat_wrapper(b, c, n, m, ns, None, None, feats, idx, only, False)
     np.testing.assert_array_equal(host(only), want_feat)
+    # a workspace the caller keeps
+    kept = torch.empty((ext.group_concat_workspace_bytes(b, c, n, m, ns),), dtype=torch.uint8, device=DEV)
+    again = torch.full((b, 3 + c, m, ns), float("nan"), device=DEV)
+    ext.group_concat_wrapper(b, c, n, m, ns, xyz, new_xyz, feats, idx, again, True, kept)
+    assert torch.equal(again, out)
 
 
 def _plant_near_twin_tie(oracle, cloud, slot, seq, around, m):
