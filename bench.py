@@ -1,25 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- SA-stack points/s per GPU on synthetic KITTI-shaped scenes (BASELINE.json's metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--pipelined 0|1] [--kind kitti|ubox|dup] [--no-graph]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--pipelined 0|1] [--kind kitti|ubox|dup|kitti_q] [--no-graph]
 
-One "step" = one pass of the 4-level set-abstraction OPERATOR stack (per level: scene index, FPS, gather, two
-ball queries, two fused groupings -- epnet_amd/sa_stack.py) over a batch of B independent 16384-point scenes
-that are already resident in HBM (default B = 256: 12.5 GB of resident buffers out of 288 GB). Steps are
-software-pipelined by default: the latency-bound sampling chain of step k runs beside the bandwidth-bound
-ball query + grouping of step k-1 (double-buffered centres / indices), every step does the full work of one
-batch; --pipelined 0 runs every step on its own (the latency figure). N > 1: launched by
-torch.distributed.run, one rank per GPU; every rank owns its own scenes (different seeds), there is NO
-collective in the data path (the ops are independent per scene), so scaling is "weak". Timing: barrier +
-synchronize on both sides of exactly K steps, MAX over ranks; rank 0 prints ONE JSON line.
+One "step" = one pass of the 4-level set-abstraction OPERATOR stack (per level: scene index, sampling [FPS + centre gather; levels
+2-4 nested in level 1 where tie-free], two ball queries, two fused groupings -- epnet_amd/sa_stack.py) over a batch of B independent
+16384-point scenes that are already resident in HBM (default B = 256: 12.5 GB of resident buffers out of 288 GB). Steps are
+software-pipelined by default: the latency-bound sampling chain of step k runs beside the bandwidth-bound ball query + grouping of
+step k-1 (double-buffered inputs / centres / indices); every step does the full work of one batch and consumes a DIFFERENT batch
+than the step before (two resident batches alternate, as a loop that takes a new batch per iteration does:
+tools/train_rcnn.py:221-223); --pipelined 0 runs every step on its own (the latency figure). N > 1: launched by
+torch.distributed.run, one rank per GPU; every rank owns its own scenes (different seeds), there is NO collective in the data path
+(the ops are independent per scene), so scaling is "weak". Timing: barrier + synchronize on both sides of exactly K steps, MAX over
+ranks; rank 0 prints ONE JSON line.
 
 Extra objects on that line:
-  roofline      the op with the largest share of the step, priced by its ALGORITHMIC bytes per launch / its
-                average duration measured with HIP events on the launch stream over an instrumented
-                (unpipelined, single-stream) run of the same K steps; `kernels` lists the same figure for every
-                op family, `roofline_hbm_bound` repeats it for the largest bandwidth-bound one (the grouping).
-  cpu_baseline  the CPU oracle (a scalar C port of the reference kernels, 1 core) timed on this host on
-                a bounded sample of the same workload.
+  roofline      the op with the largest share of the step, priced by its ALGORITHMIC bytes per launch / its average duration
+                measured with HIP events on the launch stream over an instrumented (unpipelined, single-stream) run of the same
+                K steps; `kernels` lists the same figure for every op family, `roofline_hbm_bound` repeats it for the largest
+                bandwidth-bound one (the grouping).
+  cpu_baseline  the CPU oracle (a scalar C port of the reference kernels, 1 core) timed on this host on a bounded sample of the
+                same workload.
+  verified      scene 0 of the buffers the timed steps left behind, every tensor against the oracle, each resident batch in each
+                role (verification.distinct_inputs).
+  ms_per_step_min / _median / _max   per-step durations from an event pair around every step (a loop of its own after the timed one)
+  devices_distinct, devices, per_rank_ms_per_step   what the ranks computed on (PCI address / UUID of every rank's device)
+  sampling_chain, kinds, latency_one_scene, with_fp, config5   the chain's identity share per level; the same step on the other
+                input families (uniform box, padded with exact twins, decimal-quantised); further verified measurements
 """
 import argparse
 import json

@@ -322,7 +322,9 @@ class SAStack:
     def _query_level(self, L, cur_xyz, parity):
         """the ball queries of all scales of the level: one launch over the shared index"""
         P = L["sets"][parity]
-        centre_index = self._centre_index(L, parity) if (self.ordered_query and P["index"] is not None and len(L["scales"]) <= 2) else None
+        # (the order pays from 32768 points up only -- epnet_ball_query_ordered itself ignores it below: no index is built for it there)
+        centre_index = (self._centre_index(L, parity)
+                        if (self.ordered_query and L["n"] > 16384 and P["index"] is not None and len(L["scales"]) <= 2) else None)
         if centre_index is not None:   # the centres in the order of their own scene index
             ext.ball_query_ordered_wrapper(self.batch, L["n"], L["m"], [S["radius"] for S in L["scales"]],
                                          [S["ns"] for S in L["scales"]], P["new_xyz"], cur_xyz, P["index"], centre_index,
@@ -375,7 +377,7 @@ class SAStack:
             new_xyz = self._sample_level(L, cur_xyz, 0, index_built=built)
             built = False
             nxt = self.levels[lvl + 1] if lvl + 1 < len(self.levels) else None
-            if self.ordered_query and nxt is not None and nxt["sets"][0]["index"] is not None:
+            if self.ordered_query and L["n"] > 16384 and nxt is not None and nxt["sets"][0]["index"] is not None:
                 # the ordered ball query of this level walks the index of its centres = the next level's index of its input
                 ext.scene_index_build_wrapper(self.batch, L["m"], new_xyz, nxt["sets"][0]["index"])
                 built = True

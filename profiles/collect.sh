@@ -8,7 +8,7 @@
 # usage: bash profiles/collect.sh TAG [a|b|c]  -> gpurun_out/prof_TAG/*  (copy what should be judged into profiles/)
 #        (three parts, each within one gpurun call's time limit: a = 1-3, b = per-op / FP / sweep / config 5, c = training steps)
 set -eu
-TAG=${1:-r02}
+TAG=${1:-r03}
 PART=${2:-abc}
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$ROOT/gpurun_out/prof_$TAG"
@@ -47,10 +47,16 @@ for B in 1 16 64 128 512; do python3 bench.py --cpu-scenes 0 --extras "" --batch
 python3 bench.py --cpu-scenes 0 --extras "" --batch 256 --pipelined 0 >> $OUT/sweep.jsonl
 echo "sweep done"
 # BASELINE config 5 (dense 65536-point scenes): the full line, and every kernel alone under the profiler
-python3 bench.py --config 5 --batch 128 --steps 5 --warmup 2 > $OUT/bench_config5.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_cfg5 -- python3 bench.py --config 5 --batch 128 --steps 3 --warmup 1 --cpu-scenes 0 --verify-scenes 0 --pipelined 0 --no-overlap --no-graph > $OUT/bench_config5_alone_under_rocprof.json
+python3 bench.py --config 5 --steps 5 --warmup 2 > $OUT/bench_config5.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_cfg5 -- python3 bench.py --config 5 --batch 64 --steps 3 --warmup 1 --cpu-scenes 0 --verify-scenes 0 --pipelined 0 --no-overlap --no-graph > $OUT/bench_config5_alone_under_rocprof.json
 cp $(find $OUT/stats_cfg5 -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_config5_alone.csv
+python3 profiles/summarize.py trace $(find $OUT/stats_cfg5 -name "*kernel_trace.csv" | head -1) $OUT/family_durations_config5_alone.json
 rm -rf $OUT/stats_cfg5
+# HBM bytes of the config-5 kernels (two PMC passes, every kernel alone)
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc5_fetch -- python3 bench.py --config 5 --batch 32 --steps 2 --warmup 1 --cpu-scenes 0 --verify-scenes 0 --pipelined 0 --no-overlap --no-graph > $OUT/pmc5_fetch.log
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc5_write -- python3 bench.py --config 5 --batch 32 --steps 2 --warmup 1 --cpu-scenes 0 --verify-scenes 0 --pipelined 0 --no-overlap --no-graph > $OUT/pmc5_write.log
+python3 profiles/summarize.py pmc $(find $OUT/pmc5_fetch -name "*counter_collection.csv" | head -1) $(find $OUT/pmc5_write -name "*counter_collection.csv" | head -1) 32 $OUT/pmc_traffic_config5.json
+rm -rf $OUT/pmc5_fetch $OUT/pmc5_write
 echo "config 5 done"
 fi
 if [[ $PART == *c* ]]; then

@@ -24,7 +24,8 @@ import sys
 # kernel-name prefixes (template argument lists may continue) -> op family
 FPS = {"fps_indexed_kernel<8, 32": "fps N=16384 M=4096", "fps_indexed_kernel<4, 16": "fps N=4096 M=1024",
        "fps_pruned_kernel<8, 32": "fps N=16384 M=4096", "fps_pruned_kernel<4, 16": "fps N=4096 M=1024",
-       "fps_wave_kernel<1, 16": "fps N=1024 M=256", "fps_wave_kernel<8, 2": "fps N=1024 M=256", "fps_wave_kernel<1, 4": "fps N=256 M=64"}
+       "fps_wave_kernel<1, 16": "fps N=1024 M=256", "fps_wave_kernel<8, 2": "fps N=1024 M=256", "fps_wave_kernel<1, 4": "fps N=256 M=64",
+       "fps_bigscene_kernel": "fps N=65536 M=16384"}
 
 
 def short(name):
@@ -46,9 +47,9 @@ def families(rows):
             if "group_xyz_centred" in n:
                 # one grouping CALL (epnet_group_concat_multi: both scales of the level) = the run of centred-xyz and row-gather
                 # kernels up to the next op: [xyz, xyz] without features, [xyz, xyz, lds2] with the rows staged once,
-                # [xyz, rows, xyz, rows] when the launch is too small for that
+                # [xyz, rows, xyz, rows] when the launch is too small for that, [xyz, (transpose, rows) per chunk of scenes] for rows beyond LDS
                 fam = "group"
-                while idx[-1] + 1 < len(rows) and ("group_xyz_centred" in rows[idx[-1] + 1]["name"] or "gather_rows" in rows[idx[-1] + 1]["name"]):
+                while idx[-1] + 1 < len(rows) and any(k in rows[idx[-1] + 1]["name"] for k in ("group_xyz_centred", "gather_rows", "transpose_cn")):
                     idx.append(idx[-1] + 1)
             elif "gather_rows" in n or "gather_centres" in n:
                 fam = "gather"
