@@ -740,9 +740,13 @@ static int bq_query_launch(int b, int np, int m, const BqScales<K> &sc, const fl
     const char *pair_str = getenv("EPNET_BQ_PAIR");
     const int pair_env = pair_str ? atoi(pair_str) : -1;
     const bool pair = pair_env >= 0 ? pair_env != 0 : (long long)b * m >= 65536;
+    // EPNET_BQ_PAD_KB: LDS the launch reserves without using it -- fewer workgroups per CU, i.e. wave slots left for the short
+    // one-workgroup-per-scene kernels of the sampling chain that run beside a full-chip query (an experiment knob; default 0)
+    const char *pad_str = getenv("EPNET_BQ_PAD_KB");
+    const size_t pad = pad_str ? (size_t)atoi(pad_str) * 1024 : 0;
     if (pair) {
         dim3 grid(div_up(div_up(m, 2), kQThreads / 64), b);
-#define EPNET_BQ2(D_) hipLaunchKernelGGL((bq_query2_kernel<D_, K>), grid, dim3(kQThreads), 0, s, np, m, sc, new_xyz, sorted, boxes, qboxes, order, npc)
+#define EPNET_BQ2(D_) hipLaunchKernelGGL((bq_query2_kernel<D_, K>), grid, dim3(kQThreads), pad, s, np, m, sc, new_xyz, sorted, boxes, qboxes, order, npc)
         switch (np / 2048) {
             case 1: EPNET_BQ2(1); break;
             case 2: EPNET_BQ2(2); break;
@@ -755,7 +759,7 @@ static int bq_query_launch(int b, int np, int m, const BqScales<K> &sc, const fl
         return check_launch("ball_query query");
     }
     dim3 grid(div_up(m, kQThreads / 64), b);
-#define EPNET_BQ(D_) hipLaunchKernelGGL((bq_query_kernel<D_, K>), grid, dim3(kQThreads), 0, s, np, m, sc, new_xyz, sorted, boxes, qboxes, order, npc)
+#define EPNET_BQ(D_) hipLaunchKernelGGL((bq_query_kernel<D_, K>), grid, dim3(kQThreads), pad, s, np, m, sc, new_xyz, sorted, boxes, qboxes, order, npc)
     switch (np / 2048) {
         case 1: EPNET_BQ(1); break;
         case 2: EPNET_BQ(2); break;

@@ -466,8 +466,7 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
     // Exact twins -- the reference's loader pads short scenes by re-drawing rows, kitti_rcnn_dataset.py:338-342 -- tie at the
     // round one of them is picked, harmlessly: the others sit at distance 0 from then on and cannot be sampled while the
     // maximum is positive.
-    unsigned long long holder_mask = 0ull;  // lanes that publish this wave's maximum
-    unsigned long long multi_mask = 0ull;   // lanes holding it in several of their slots with DIFFERENT coordinates
+    bool wave_multi = false;  // several points of this wave hold its maximum
     int tied_v = 0x7fffffff;  // wave-uniform, kept scalar
     // one round; kTies: also look for a second holder of the round's maximum (only the rounds a later level can ask about pay
     // for that: the two instantiations of the body are run one after the other)
@@ -509,7 +508,6 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
             unsigned cand = fold_parts<PPT>(__ballot(bm == wbest));
             racc = 0xFFFFFFFFu;
             hbuckets = 0ull;
-            bool mixed = false;
             do {
                 const int j = (int)__builtin_ctz(cand);
                 cand &= cand - 1u;
@@ -519,8 +517,6 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
                 __builtin_amdgcn_sched_barrier(0);  // one GPR-index window for the four slot registers
                 const unsigned r = tj == wbest ? ((rw >> ((j & 1) << 4)) & 0xFFFFu) : 0xFFFFFFFFu;
                 if (r != 0xFFFFFFFFu) hbuckets |= 1ull << ((lane & ~(PPT - 1)) | j);  // summary lane of (slot j, my part)
-                if (kTies)   // a second held slot of this lane with other coordinates than the first (equality is transitive)
-                    mixed = mixed || (r != 0xFFFFFFFFu && racc != 0xFFFFFFFFu && (xj != xa || yj != ya || zj != za));
                 const bool take = r < racc;  // a lane holding the maximum in two of its slots keeps the smaller rank
                 racc = take ? r : racc;
                 xa = take ? xj : xa;
@@ -533,8 +529,8 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
             }
             if (kTies) {
                 // (hbuckets has one bit per slot in which the lane holds the maximum)
-                holder_mask = __ballot(hbuckets != 0ull);
-                multi_mask = __ballot(mixed);
+                const unsigned long long holders = __ballot(hbuckets != 0ull);
+                wave_multi = (holders & (holders - 1ull)) != 0ull || __ballot((hbuckets & (hbuckets - 1ull)) != 0ull) != 0ull;
             }
         }
         const int buf = it & 1;
@@ -555,13 +551,32 @@ __device__ __forceinline__ void fps_rounds(int m, const VF &x, const VF &y, cons
         cy = rec.y;
         cz = rec.z;
         if (kTies) {
-            // this wave's (exact, possibly cached) maximum equals the winner's distance, and one of its holders is not the
-            // winner's exact twin (the winner's own lane compares equal to itself): a tie that picks between coordinates.
-            // Branch-free (a scalar branch here would put a VALU -> SALU round trip on every wave's critical path)
-            const unsigned long long differs = __ballot(xa != cx || ya != cy || za != cz);   // (stale in non-holders: masked)
-            const bool other = ((differs & holder_mask) | multi_mask) != 0ull;
+            // this wave's (exact, possibly cached) maximum equals the winner's distance and the winner is not its only holder: a
+            // tie -- unless every other holder is an exact twin of the winner. The first test is what every round pays (a handful
+            // of instructions; the twin rule computed branch-free on every round cost 0.1 us on each of the 1024 watched rounds of
+            // the level-1 sampling: 2.05 -> 2.15 ms); the coordinates are compared behind a wave-uniform branch that only a round
+            // with several holders takes.
+            const bool mine = (int)((klo & 1023u) >> 6) == wave;
             const int wd = (int)(unsigned)(kfull >> 32);
-            tied_v = min(tied_v, __builtin_amdgcn_readfirstlane(((wbest == wd && other) || wd == 0) ? it : 0x7fffffff));  // an SGPR
+            const bool suspect = (wbest == wd && (!mine || wave_multi)) || wd == 0;
+            if (__builtin_amdgcn_readfirstlane(suspect ? 1 : 0)) {
+                // every slot in which a lane holds the maximum (bit (lane's part | j) of hbuckets) against the winner's coordinates
+                // (the winner's own slot compares equal to itself)
+                bool differs = false;
+                const unsigned mine_slots = (unsigned)((hbuckets >> (lane & ~(PPT - 1))) & ((1ull << PPT) - 1ull));   // (PPT <= 32)
+                unsigned any_slots = mine_slots;   // slots in which ANY lane of the wave holds the maximum
+                for (int off = 32; off >= 1; off >>= 1) any_slots |= (unsigned)__shfl_xor((int)any_slots, off, 64);
+                // a runtime loop with indexed registers: one copy of the code, no registers beyond the round's own
+#pragma unroll 1
+                while (any_slots) {
+                    const int j = (int)__builtin_ctz(any_slots);
+                    any_slots &= any_slots - 1u;
+                    const float xj = x[j], yj = y[j], zj = z[j];
+                    __builtin_amdgcn_sched_barrier(0);
+                    differs = differs || (((mine_slots >> j) & 1u) && (xj != cx || yj != cy || zj != cz));
+                }
+                if (wd == 0 || __ballot(differs)) tied_v = min(tied_v, it);
+            }
         }
         const int kb2 = kb == 0 ? 2 : kb - 1;  // == (it + 2) % 3: last read in round it-1, next used in round it+2
         kb = kb == 2 ? 0 : kb + 1;
