@@ -125,3 +125,45 @@ def test_ordered_falls_back_without_a_centre_index(oracle):
     out = [torch.full((b, m, 16), -5, dtype=torch.int32, device=DEV)]
     ext.ball_query_ordered_wrapper(b, n, m, [0.8], [16], d_c, d_xyz, ext.scene_index(d_xyz), None, out)
     np.testing.assert_array_equal(host(out[0]), oracle.ball_query(0.8, 16, xyz, centres))
+
+
+def test_ordered_entry_point_contract(oracle):
+    """the C entry point itself: empty launches are no-ops, an undersized index is refused (as the other indexed entry points
+    do), three scales fall back to one launch per scale, NULL centre index = the plain indexed query"""
+    import ctypes
+    from epnet_amd import _lib, pointnet2_cuda as ext
+    lib = _lib.lib()
+    b, n, m, ns = 1, 32768, 1024, 16
+    xyz = _cloud("kitti", b, n, seed=1)
+    centres = _centres(oracle, xyz, m, "subset", seed=1)
+    d_xyz, d_c = dev(xyz), dev(centres)
+    index, cindex = ext.scene_index(d_xyz), ext.scene_index(d_c)
+    out = torch.full((b, m, ns), -5, dtype=torch.int32, device=DEV)
+    radii = (ctypes.c_float * 1)(0.6)
+    nss = (ctypes.c_int * 1)(ns)
+    ptrs = (ctypes.c_void_p * 1)(out.data_ptr())
+    s = torch.cuda.current_stream().cuda_stream
+
+    def call(bb, mm, ix_bytes, cix_ptr, cix_bytes):
+        return lib.epnet_ball_query_ordered(bb, n, mm, 1, ctypes.cast(radii, ctypes.c_void_p), ctypes.cast(nss, ctypes.c_void_p),
+                                            d_c.data_ptr(), d_xyz.data_ptr(), index.data_ptr(), ix_bytes, cix_ptr, cix_bytes,
+                                            ctypes.cast(ptrs, ctypes.c_void_p), s)
+    assert call(0, m, index.numel(), cindex.data_ptr(), cindex.numel()) == 0          # no scenes
+    assert call(b, 0, index.numel(), cindex.data_ptr(), cindex.numel()) == 0          # no centres
+    torch.cuda.synchronize()
+    assert (out == -5).all()
+    assert call(b, m, index.numel() - 16, cindex.data_ptr(), cindex.numel()) != 0     # undersized point index
+    assert call(b, m, index.numel(), cindex.data_ptr(), cindex.numel() - 16) != 0     # undersized centre index
+    assert call(b, m, index.numel(), None, 0) == 0                                    # no centre index: the plain indexed query
+    torch.cuda.synchronize()
+    want = oracle.ball_query(0.6, ns, xyz, centres)
+    np.testing.assert_array_equal(host(out), want)
+    out.fill_(-5)
+    assert call(b, m, index.numel(), cindex.data_ptr(), cindex.numel()) == 0
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(host(out), want)
+    # three scales: one launch per scale through the same entry point
+    outs = [torch.full((b, m, k), -5, dtype=torch.int32, device=DEV) for k in (4, 8, 16)]
+    ext.ball_query_ordered_wrapper(b, n, m, [0.3, 0.6, 1.2], [4, 8, 16], d_c, d_xyz, index, cindex, outs)
+    for r, k, got in zip((0.3, 0.6, 1.2), (4, 8, 16), outs):
+        np.testing.assert_array_equal(host(got), oracle.ball_query(r, k, xyz, centres))
