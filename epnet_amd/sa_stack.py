@@ -155,7 +155,9 @@ class SAStack:
             index_bytes = ext.scene_index_bytes(batch, cur) if shared_index else 0
             L = {
                 "n": cur, "m": m, "c": c,
-                "xyz_t": torch.empty((batch, 3, cur), dtype=f32, device=dev),
+                # the flipped cloud of the unfused composition (pointnet2_modules.py:30): written by stage S, read by the grouping of
+                # stage G one step later -- one per ring slot, like the centres
+                "xyz_t_sets": [torch.empty((batch, 3, cur), dtype=f32, device=dev) for _ in range(self.ring if not fused else 1)],
                 "temp": torch.empty((batch, cur), dtype=f32, device=dev),
                 # (two stages: the sampling chain of one batch writes all levels in one go -- one tensor; three: S1 of batch k writes
                 # level 1 while S2 of batch k-1 still reads its own)
@@ -272,7 +274,7 @@ class SAStack:
             ext.scene_index_build_wrapper(b, n, cur_xyz, P["index"])
         if self.fused_sampling:   # FPS + gather of the centres in one kernel (epnet_sample_centres)
             if not self.fused:
-                L["xyz_t"].copy_(cur_xyz.transpose(1, 2))
+                L["xyz_t_sets"][parity].copy_(cur_xyz.transpose(1, 2))
             if self.chain:
                 prefix_in = self.levels[lvl - 1]["sets"][parity]["prefix"] if lvl > 0 else None
                 nxt = self.levels[lvl + 1]["m"] if lvl + 1 < len(self.levels) else 1
@@ -286,13 +288,13 @@ class SAStack:
             else:
                 ext.sample_centres_wrapper(b, n, m, cur_xyz, P["index"], L["fps_idx_sets"][parity], P["new_xyz"])
         else:                     # the reference module's sequence, op by op
-            L["xyz_t"].copy_(cur_xyz.transpose(1, 2))            # pointnet2_modules.py:30
+            L["xyz_t_sets"][parity if not self.fused else 0].copy_(cur_xyz.transpose(1, 2))            # pointnet2_modules.py:30
             L["temp"].fill_(1e10)                                # pointnet2_utils.py:26
             if P["index"] is not None:
                 ext.furthest_point_sampling_indexed_wrapper(b, n, m, cur_xyz, P["index"], L["temp"], L["fps_idx_sets"][parity])
             else:
                 ext.furthest_point_sampling_wrapper(b, n, m, cur_xyz, L["temp"], L["fps_idx_sets"][parity])
-            ext.gather_points_wrapper(b, 3, n, m, L["xyz_t"], L["fps_idx_sets"][parity], L["new_xyz_t"])
+            ext.gather_points_wrapper(b, 3, n, m, L["xyz_t_sets"][parity if not self.fused else 0], L["fps_idx_sets"][parity], L["new_xyz_t"])
             P["new_xyz"].copy_(L["new_xyz_t"].transpose(1, 2))    # pointnet2_modules.py:42-45
         return P["new_xyz"]
 
@@ -315,7 +317,7 @@ class SAStack:
             ext.group_concat_wrapper(b, L["c"], n, m, S["ns"], cur_xyz, L["sets"][parity]["new_xyz"], L["features"],
                                      self._idx(S, parity), S["grouped"], True, S.get("workspace"))
         else:
-            ext.group_points_wrapper(b, 3, n, m, S["ns"], L["xyz_t"], self._idx(S, parity), S["grouped_xyz"])
+            ext.group_points_wrapper(b, 3, n, m, S["ns"], L["xyz_t_sets"][parity], self._idx(S, parity), S["grouped_xyz"])
             if L["c"]:
                 ext.group_points_wrapper(b, L["c"], n, m, S["ns"], L["features"], self._idx(S, parity), S["grouped_feat"])
 

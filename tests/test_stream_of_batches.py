@@ -158,6 +158,23 @@ def test_loader_fills_the_input_buffer_in_place(oracle):
     assert bench.verify_scene(stack, batches[2], 0, prev_xyz=batches[0]) == []
 
 
+def test_unfused_composition_on_a_stream_of_different_batches(oracle):
+    """--unfused (the reference's op-by-op grouping: flipped cloud, group_points, no centre subtraction) pipelined: the flipped
+    cloud stage S writes is read by stage G one step later, so it is double-buffered like the centres (the bench's flag sweep of
+    round 3 found it single-buffered: level-1 grouped_xyz of the wrong batch)"""
+    import bench
+    from epnet_amd import sa_stack
+    b, n = 1, 16384
+    kinds, batches = _batches(oracle, b, n)
+    stack = sa_stack.SAStack(b, n=n, device=DEV, seed=5, pipelined=True, fused_sampling=True, fused=False)
+    stack.capture(batches[0])
+    stack.replay(batches[0])
+    for k in range(1, 4):
+        stack.replay(batches[k])
+        torch.cuda.synchronize()
+        assert bench.verify_scene(stack, batches[k], 0, prev_xyz=batches[k - 1]) == [], (kinds[k - 1], kinds[k])
+
+
 @pytest.mark.parametrize("with_fp", [False, True])
 def test_eager_pipelined_steps_on_different_batches(oracle, with_fp):
     import bench
