@@ -9,7 +9,11 @@ tests, no nvcc) -- they do not change "parity unpinned", they lower the risk tha
   * rotated-rectangle overlap: the reference collects edge intersections and inside corners, sorts them by angle and
     sums triangle areas in float32 (iou3d_kernel.cu:108-212). Here the overlap is the area of rectangle A clipped
     against the four half-planes of rectangle B (Sutherland-Hodgman) in float64;
-  * hand-derived known answers for the tie-break across every block size and for NMS suppression chains.
+  * hand-derived known answers for the tie-break across every block size and for NMS suppression chains;
+  * round 3: the scan kernels in closed form -- ball query (mask + stable sort of a whole distance matrix instead of the sequential
+    scan with early exit, ball_query_gpu.cu:9-45), three_nn (stable argsort = the strict-'<' insertion's (d, k) order,
+    interpolate_gpu.cu:30-48), gather / grouping / interpolation and their gradients by numpy indexing; and the nesting of furthest
+    point sampling through exact twins (what the sampling chain's twin rule rests on).
 """
 import math
 
@@ -310,3 +314,101 @@ def test_nms_suppression_chains_by_hand(oracle):
     long = np.array([[0.3 * i, 0.0, 0.3 * i + 1.0, 1.0, 0.0] for i in range(130)], np.float32)
     assert oracle.nms(long, 0.5, False).tolist() == list(range(0, 130, 2))
     assert oracle.nms(long, 0.5, True).tolist() == list(range(0, 130, 2))
+
+
+# ------------------------------------------------------------------------------------------------ the scan kernels, closed form
+# The C oracle walks the reference's loops (one thread per centre / unknown, k = 0 .. n-1, early exit). Here the same results are
+# derived from whole distance matrices with numpy: selections by sorting / masking instead of sequential scans. float32 arithmetic
+# in the reference's association: (dx*dx + dy*dy) + dz*dz.
+
+def _d2_matrix(a, b):
+    """(len(a), len(b)) squared distances, float32, (ax-bx)*(ax-bx) + (ay-by)*(ay-by) + (az-bz)*(az-bz) left to right"""
+    dx = a[:, None, 0] - b[None, :, 0]
+    dy = a[:, None, 1] - b[None, :, 1]
+    dz = a[:, None, 2] - b[None, :, 2]
+    d = (dx * dx + dy * dy) + dz * dz
+    assert d.dtype == np.float32
+    return d
+
+
+def ball_query_closed_form(radius, nsample, xyz, new_xyz):
+    """ball_query_gpu.cu:9-45: the first nsample points with d2 < radius^2 in index order, the rest of the row filled with the first
+    hit; a ball without a hit keeps the zeros its tensor was created with (pointnet2_utils.py:221)"""
+    r2 = np.float32(radius) * np.float32(radius)
+    out = np.zeros((xyz.shape[0], new_xyz.shape[1], nsample), np.int32)
+    for b in range(xyz.shape[0]):
+        inside = _d2_matrix(new_xyz[b], xyz[b]) < r2
+        order = np.argsort(~inside, axis=1, kind="stable")[:, :nsample]          # hits first, each group in index order
+        count = inside.sum(axis=1)
+        first = order[:, 0]
+        row = np.where(np.arange(nsample)[None, :] < count[:, None], order, first[:, None])
+        out[b] = np.where(count[:, None] > 0, row, 0)
+    return out
+
+
+def three_nn_closed_form(unknown, known):
+    """interpolate_gpu.cu:30-48: a strict-'<' insertion over k = 0 .. m-1 keeps the three smallest (d, k) pairs in
+    lexicographic order"""
+    bsz, n, m = unknown.shape[0], unknown.shape[1], known.shape[1]
+    d_out = np.empty((bsz, n, 3), np.float32)
+    i_out = np.empty((bsz, n, 3), np.int32)
+    for b in range(bsz):
+        d = _d2_matrix(unknown[b], known[b])
+        order = np.argsort(d, axis=1, kind="stable")[:, :3]                      # stable: equal distances by index
+        d_out[b] = np.take_along_axis(d, order, axis=1)
+        i_out[b] = order
+    return d_out, i_out
+
+
+@pytest.mark.parametrize("n,m,radius,ns,kind", [(3000, 400, 0.8, 16, "kitti"), (2048, 256, 0.3, 32, "kitti"), (500, 77, 50.0, 8, "ubox"),
+                                                (1500, 300, 1e-4, 4, "dup"), (700, 64, 3.0, 64, "lattice")])
+def test_ball_query_scan_equals_the_closed_form(oracle, n, m, radius, ns, kind):
+    from epnet_amd import synth
+    xyz = (np.stack([clouds_with_duplicates(n, 7), clouds_with_duplicates(n, 8)]) if kind == "lattice"
+           else synth.scenes(kind, 2, n, seed=31).numpy())
+    rng = np.random.default_rng(n)
+    centres = np.ascontiguousarray(xyz[:, rng.permutation(n)[:m]]) + (np.float32(0.01) if kind == "kitti" else np.float32(0))
+    got = oracle.ball_query(radius, ns, xyz, centres)
+    np.testing.assert_array_equal(got, ball_query_closed_form(radius, ns, xyz, centres))
+    if kind == "dup":                       # a tiny ball around a duplicated point: exactly the twins, padded with the first
+        assert (got[:, :, 0] >= 0).all() and ((got == got[:, :, :1]).any(axis=2)).all()
+
+
+@pytest.mark.parametrize("n,m,kind", [(2000, 500, "kitti"), (1024, 64, "ubox"), (900, 300, "lattice"), (300, 3, "kitti")])
+def test_three_nn_scan_equals_the_closed_form(oracle, n, m, kind):
+    from epnet_amd import synth
+    src = (np.stack([clouds_with_duplicates(n + m, 5), clouds_with_duplicates(n + m, 6)]) if kind == "lattice"
+           else synth.scenes(kind, 2, n + m, seed=17).numpy())
+    unknown, known = np.ascontiguousarray(src[:, :n]), np.ascontiguousarray(src[:, n:])
+    d2, idx = oracle.three_nn(unknown, known)
+    want_d, want_i = three_nn_closed_form(unknown, known)
+    np.testing.assert_array_equal(idx, want_i)              # lattice clouds: many equal distances, the smaller index first
+    np.testing.assert_array_equal(d2, want_d)
+
+
+def test_gather_group_interpolate_equal_numpy_indexing(oracle):
+    rng = np.random.default_rng(3)
+    b, c, n, m, ns = 2, 7, 300, 40, 5
+    feats = rng.standard_normal((b, c, n)).astype(np.float32)
+    idx = rng.integers(0, n, size=(b, m, ns)).astype(np.int32)
+    want = np.stack([feats[s][:, idx[s]] for s in range(b)])                      # (b, c, m, ns)
+    np.testing.assert_array_equal(oracle.group_points(feats, idx), want)
+    np.testing.assert_array_equal(oracle.gather_points(feats, idx[:, :, 0].copy()), want[:, :, :, 0])
+    grad = rng.standard_normal((b, c, m, ns)).astype(np.float32)
+    acc = np.zeros((b, c, n), np.float64)
+    for s in range(b):
+        for ch in range(c):
+            np.add.at(acc[s, ch], idx[s].ravel(), grad[s, ch].ravel().astype(np.float64))
+    np.testing.assert_allclose(oracle.group_points_grad(grad, idx, n), acc, rtol=1e-5, atol=1e-5)
+    nn = rng.integers(0, n, size=(b, m, 3)).astype(np.int32)
+    w = rng.random((b, m, 3)).astype(np.float32)
+    p = np.stack([feats[s][:, nn[s]] for s in range(b)])                          # (b, c, m, 3)
+    want_i = (p[..., 0] * w[:, None, :, 0] + p[..., 1] * w[:, None, :, 1]) + p[..., 2] * w[:, None, :, 2]   # interpolate_gpu.cu:86-106
+    np.testing.assert_array_equal(oracle.three_interpolate(feats, nn, w), want_i.astype(np.float32))
+    gout = rng.standard_normal((b, c, m)).astype(np.float32)
+    acc = np.zeros((b, c, n), np.float64)
+    for s in range(b):
+        for ch in range(c):
+            for k in range(3):
+                np.add.at(acc[s, ch], nn[s, :, k], (gout[s, ch] * w[s, :, k]).astype(np.float64))
+    np.testing.assert_allclose(oracle.three_interpolate_grad(gout, nn, w, n), acc, rtol=1e-5, atol=1e-5)
