@@ -120,6 +120,9 @@ __global__ __launch_bounds__(kBqThreads) void ball_query_kernel(int n, int m, fl
 
 // T threads, 2^BITS grid cells: <1024, 14> for big scenes; <256, 12> for n <= 4096, where 4096 cells are plenty and a
 // workgroup of 4 waves with 18 KB of LDS finds room on a CU that the wide kernels of the pipelined stack occupy
+#ifdef EPNET_BQ_STATS  // diagnostic build only (profiles/micro/bq_stats.py): per-wave counters of bq_query2_kernel
+__device__ unsigned long long g_bq_stats[16];
+#endif
 #ifdef EPNET_IX_STATS  // diagnostic build only (profiles/micro/ix_stats.py): phase counters of the index build (wave 0)
 __device__ unsigned long long g_ix_stats[8];
 #define EPNET_IX_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
@@ -443,6 +446,39 @@ __device__ __forceinline__ void bq_emit_list(int lane, const int *hits, int cnt,
     for (int l = cnt + lane; l < nsample; l += 64) out[l] = first;
 }
 
+// 64 < cnt <= 64 * RM hits in `hits`, nsample <= 64: only the nsample SMALLEST original indices are wanted. They are found
+// without a second walk: the indices are distinct integers below np, so count(hits < T) grows by at most one per unit of T and a
+// binary search over T finds the threshold below which exactly nsample of them lie (the lanes hold the list in RM registers; a
+// count is RM ballots); those are compacted to the head of the list, which bq_emit_list then orders.
+template <int RM>
+__device__ __forceinline__ int bq_select_smallest(int lane, int *hits, int cnt, int nsample, int np) {
+    __builtin_amdgcn_wave_barrier();
+    int key[RM];
+#pragma unroll
+    for (int r = 0; r < RM; ++r) key[r] = (r * 64 < cnt && r * 64 + lane < cnt) ? hits[r * 64 + lane] : 0x7fffffff;
+    int lo = 0, hi = np;   // count(hits < lo) < nsample <= count(hits < hi)
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        int c = 0;
+#pragma unroll
+        for (int r = 0; r < RM; ++r)
+            if (r * 64 < cnt) c += (int)__popcll(__ballot(key[r] < mid));
+        if (c >= nsample) hi = mid;
+        else lo = mid;
+    }
+    __builtin_amdgcn_wave_barrier();
+    int base = 0;
+#pragma unroll
+    for (int r = 0; r < RM; ++r)
+        if (r * 64 < cnt) {
+            const bool sel = key[r] < hi;
+            const unsigned long long sm = __ballot(sel);
+            if (sel) hits[base + popc_below(sm)] = key[r];
+            base += (int)__popcll(sm);
+        }
+    return hi;   // every kept index is below, every dropped one at or above
+}
+
 // a crowded ball: every hit sets bit `original index` of an N-bit bitmap, which is then read back in order
 template <int DPL>
 __device__ __forceinline__ void bq_bitmap_search(int lane, int np, float r2, int nsample, float cx, float cy, float cz,
@@ -556,16 +592,23 @@ __global__ __launch_bounds__(kQThreads) void bq_query_kernel(int np, int m, BqSc
 // holds at most 8 waves per SIMD, so a wave that walks the chain for two centres at once -- quad boxes loaded once
 // and tested against both, the bucket boxes of centre 0 in lanes 0-31 and of centre 1 in lanes 32-63, one candidate
 // row of each per step -- halves the latency per centre. Same results as bq_query_kernel.
-template <int DPL, int K>
+// kStream (every nsample <= 64; the launcher takes it for scenes of more than 16384 points): no bitmap. A list that runs full
+// during the walk is cut down to its nsample smallest indices on the spot and from then on only takes hits below the threshold
+// of that cut (nothing at or above it can be among the first nsample in index order): ONE walk however crowded the ball, and
+// 4 KB of LDS per wave instead of the N-bit bitmap's 8 KB at 65536 points, which held the kernel at half the waves a CU can
+// keep (the walk is a chain of dependent loads: 0.54 -> 0.32 ms at 32 scenes of BASELINE config 5). The lists are looked at once
+// per step of the walk (<= 2 rows = 128 appends per list).
+template <int DPL, int K, bool kStream>
 __global__ __launch_bounds__(kQThreads) void bq_query2_kernel(int np, int m, BqScales<K> sc,
                                                               const float *__restrict__ new_xyz,
                                                               const float4 *__restrict__ sorted,
                                                               const float *__restrict__ boxes,
                                                               const float *__restrict__ qboxes,
                                                               const float4 *__restrict__ order, int npc) {
-    __shared__ unsigned s_bits[kQThreads / 64][64 * DPL];
+    constexpr int CAP = kStream ? (K == 1 ? 512 : 256) : 64, kStepAppends = 128;
+    constexpr int kBitWords = kStream ? 0 : 64 * DPL;
+    __shared__ unsigned s_pool[kQThreads / 64][kBitWords + 2 * K * CAP];   // (the bitmap of a crowded ball,) the hit lists
     __shared__ int s_quads[kQThreads / 64][2][64];
-    __shared__ int s_hits[kQThreads / 64][2][K][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int wg_x, bs;
     xcd_scene_map(wg_x, bs);   // a scene's index passes through one XCD's L2
@@ -594,31 +637,61 @@ __global__ __launch_bounds__(kQThreads) void bq_query2_kernel(int np, int m, BqS
     float r2max = sc.r2[0];
 #pragma unroll
     for (int k = 1; k < K; ++k) r2max = fmaxf(r2max, sc.r2[k]);
-    int cnt[2][K];
+    int cnt[2][K];    // hits so far (kStream: entries in the list)
+    int below[2][K];  // (kStream) the list only takes original indices below this
 #pragma unroll
     for (int e = 0; e < 2; ++e)
 #pragma unroll
-        for (int k = 0; k < K; ++k) cnt[e][k] = 0;
+        for (int k = 0; k < K; ++k) {
+            cnt[e][k] = 0;
+            below[e][k] = 0x7fffffff;
+        }
+    int *hits_of = reinterpret_cast<int *>(s_pool[wave]) + kBitWords;
+#ifdef EPNET_BQ_STATS
+    const unsigned long long st_0 = __builtin_amdgcn_s_memtime();
+    unsigned st_rows = 0;
+    bool st_sel = false, st_again = false;
+#endif
 
     auto visit = [&](int e, const float4 &p) {  // e is compile-time at the call sites
+#ifdef EPNET_BQ_STATS
+        ++st_rows;
+#endif
         const float cx = e ? bx_ : ax, cy = e ? by_ : ay, cz = e ? bz_ : az;
         const float dx = cx - p.x, dy = cy - p.y, dz = cz - p.z;
         const float d2 = dx * dx + dy * dy + dz * dz;
         if (!__ballot(d2 < r2max)) return;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            const bool hit = d2 < sc.r2[k];
+            const bool hit = d2 < sc.r2[k] && (!kStream || __float_as_int(p.w) < below[e][k]);
             const unsigned long long hm = __ballot(hit);
             if (hm) {
                 const int pos = cnt[e][k] + popc_below(hm);
-                if (hit && pos < 64) s_hits[wave][e][k][pos] = __float_as_int(p.w);
+                if (hit && pos < CAP) hits_of[(e * K + k) * CAP + pos] = __float_as_int(p.w);
                 cnt[e][k] += (int)__popcll(hm);
             }
+        }
+    };
+    // (kStream) between two steps of the walk: room for the next step's appends in every list
+    auto make_room = [&]() {
+        if constexpr (kStream) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+                    if (cnt[e][k] > CAP - kStepAppends) {
+                        below[e][k] = bq_select_smallest<CAP / 64>(lane, hits_of + (e * K + k) * CAP, cnt[e][k], sc.nsample[k], np);
+                        cnt[e][k] = sc.nsample[k];
+#ifdef EPNET_BQ_STATS
+                        st_sel = true;
+#endif
+                    }
         }
     };
     // one candidate row of each centre per step (both loads in flight together); bucket_of(e, bit)
     auto scan_pairs = [&](unsigned long long cand0, unsigned long long cand1, auto &&bucket_of) {
         while (cand0 | cand1) {
+            make_room();
             float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0, p2 = p0, p3 = p0;
             const bool h0 = cand0 != 0ull, h1 = cand1 != 0ull;
             if (h0) { p0 = sorted[(bucket_of(0, (int)__builtin_ctzll(cand0)) << 6) + lane]; cand0 &= cand0 - 1ull; }
@@ -670,6 +743,9 @@ __global__ __launch_bounds__(kQThreads) void bq_query2_kernel(int np, int m, BqS
             __builtin_amdgcn_wave_barrier();
         }
     }
+#ifdef EPNET_BQ_STATS
+    const unsigned long long st_1 = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         if (e == 1 && !two) break;
@@ -677,13 +753,42 @@ __global__ __launch_bounds__(kQThreads) void bq_query2_kernel(int np, int m, BqS
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             int *out = sc.idx[k] + ((size_t)bs * m + (e ? out1 : out0)) * sc.nsample[k];
-            if (cnt[e][k] <= 64)
-                bq_emit_list(lane, s_hits[wave][e][k], cnt[e][k], sc.nsample[k], out);
-            else
-                bq_bitmap_search<DPL>(lane, np, sc.r2[k], sc.nsample[k], cx, cy, cz, sorted, boxes, qboxes, out, s_bits[wave],
-                                      s_quads[wave][0]);
+            int *hits = hits_of + (e * K + k) * CAP;
+            if constexpr (kStream) {
+                if (cnt[e][k] > 64) {   // (a list that was cut before holds nsample or more candidates: the same selection)
+                    bq_select_smallest<CAP / 64>(lane, hits, cnt[e][k], sc.nsample[k], np);
+                    cnt[e][k] = sc.nsample[k];
+#ifdef EPNET_BQ_STATS
+                    st_sel = true;
+#endif
+                }
+                bq_emit_list(lane, hits, cnt[e][k], sc.nsample[k], out);
+            } else {
+                if (cnt[e][k] <= 64) {
+                    bq_emit_list(lane, hits, cnt[e][k], sc.nsample[k], out);
+                } else {
+#ifdef EPNET_BQ_STATS
+                    st_again = true;
+#endif
+                    bq_bitmap_search<DPL>(lane, np, sc.r2[k], sc.nsample[k], cx, cy, cz, sorted, boxes, qboxes, out, s_pool[wave],
+                                          s_quads[wave][0]);
+                }
+            }
         }
     }
+#ifdef EPNET_BQ_STATS
+    {
+        const unsigned long long st_3 = __builtin_amdgcn_s_memtime();
+        if (lane == 0) {
+            const int o = st_again ? 8 : (st_sel ? 4 : 0);   // plain waves / waves that selected / waves that walked again
+            atomicAdd(&g_bq_stats[o + 0], 1ull);
+            atomicAdd(&g_bq_stats[o + 1], st_1 - st_0);
+            atomicAdd(&g_bq_stats[o + 2], st_3 - st_1);
+            atomicAdd(&g_bq_stats[o + 3], (unsigned long long)st_rows);
+            atomicMax(&g_bq_stats[12], st_3 - st_0);
+        }
+    }
+#endif
 }
 
 }  // namespace epnet
@@ -746,7 +851,20 @@ static int bq_query_launch(int b, int np, int m, const BqScales<K> &sc, const fl
     const size_t pad = pad_str ? (size_t)atoi(pad_str) * 1024 : 0;
     if (pair) {
         dim3 grid(div_up(div_up(m, 2), kQThreads / 64), b);
-#define EPNET_BQ2(D_) hipLaunchKernelGGL((bq_query2_kernel<D_, K>), grid, dim3(kQThreads), pad, s, np, m, sc, new_xyz, sorted, boxes, qboxes, order, npc)
+        // streaming lists instead of the bitmap (see the kernel): where the bitmap costs occupancy, i.e. above 16384 points;
+        // EPNET_BQ_STREAM=0/1 forces either (nsample <= 64 is a precondition of the streaming variant)
+        bool stream = np > 16384;
+        if (const char *e = getenv("EPNET_BQ_STREAM")) stream = atoi(e) != 0;
+        for (int k = 0; k < K; ++k) stream = stream && sc.nsample[k] <= 64;
+#define EPNET_BQ2(D_)                                                                                                                   \
+    do {                                                                                                                                \
+        if (stream)                                                                                                                     \
+            hipLaunchKernelGGL((bq_query2_kernel<D_, K, true>), grid, dim3(kQThreads), pad, s, np, m, sc, new_xyz, sorted, boxes, qboxes, \
+                               order, npc);                                                                                             \
+        else                                                                                                                            \
+            hipLaunchKernelGGL((bq_query2_kernel<D_, K, false>), grid, dim3(kQThreads), pad, s, np, m, sc, new_xyz, sorted, boxes,       \
+                               qboxes, order, npc);                                                                                     \
+    } while (0)
         switch (np / 2048) {
             case 1: EPNET_BQ2(1); break;
             case 2: EPNET_BQ2(2); break;
@@ -898,6 +1016,14 @@ extern "C" int epnet_ball_query_ws(int b, int n, int m, float radius, int nsampl
     return epnet_ball_query_indexed(b, n, m, radius, nsample, new_xyz, xyz, workspace, workspace_bytes, idx, stream);
 }
 
+#ifdef EPNET_BQ_STATS
+extern "C" int epnet_debug_bq_stats(unsigned long long *host16) {
+    (void)hipMemcpyFromSymbol(host16, HIP_SYMBOL(epnet::g_bq_stats), sizeof(unsigned long long) * 16);
+    unsigned long long zero[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(epnet::g_bq_stats), zero, sizeof(zero));
+    return 0;
+}
+#endif
 #ifdef EPNET_IX_STATS
 extern "C" int epnet_debug_ix_stats(unsigned long long *host8) {
     (void)hipMemcpyFromSymbol(host8, HIP_SYMBOL(epnet::g_ix_stats), sizeof(unsigned long long) * 8);

@@ -335,6 +335,37 @@ def test_ball_query_writes_every_slot_and_boundary_is_strict(oracle):
     assert host(idx).tolist() == [[[63, 64, 65, 63, 63, 63], [0, 0, 0, 0, 0, 0]]]
 
 
+@pytest.mark.parametrize("n,order", [(16384, "descending"), (16384, "ascending"), (16384, "random"), (2048, "descending"), (65536, "descending")])
+@pytest.mark.parametrize("pair,stream", [("0", "0"), ("1", "0"), ("1", "1")])
+def test_ball_query_crowded_lists_keep_the_smallest_indices(oracle, n, order, pair, stream, monkeypatch):
+    """balls that hold thousands of points. The streaming variant of the pair kernel (the library's choice above 16384 points,
+    forced here on every size) cuts a hit list that runs full during the walk down to its nsample smallest ORIGINAL indices, again
+    and again, with a threshold for what the list takes afterwards; the other kernels walk a second time through a bitmap.
+    `descending`: the walk (cell order: along x) meets the largest indices first, so every cut replaces the whole list;
+    `ascending`: the first cut already holds the answer; nsample 1 .. 64, and 100 (beyond a list: always the bitmap pass)"""
+    from epnet_amd import pointnet2_cuda as ext
+    monkeypatch.setenv("EPNET_BQ_PAIR", pair)
+    monkeypatch.setenv("EPNET_BQ_STREAM", stream)
+    rng = np.random.default_rng(n)
+    xyz = (rng.random((1, n, 3)) * np.array([40.0, 1.0, 1.0])).astype(np.float32)
+    perm = {"ascending": np.argsort(xyz[0, :, 0]), "descending": np.argsort(-xyz[0, :, 0]), "random": rng.permutation(n)}[order]
+    xyz = np.ascontiguousarray(xyz[:, perm])
+    m = 37
+    centres = np.ascontiguousarray(xyz[:, rng.permutation(n)[:m]])
+    centres[0, -1] = (20.0, 0.5, 0.5)
+    d_xyz, d_c = dev(xyz), dev(centres)
+    index = ext.scene_index(d_xyz)
+    scales = ((6.0, 64), (9.0, 1)), ((3.0, 5), (50.0, 33)), ((7.0, 100), (2.0, 64))
+    for sc in scales:
+        outs = [torch.full((1, m, ns), -5, dtype=torch.int32, device=DEV) for _r, ns in sc]
+        ext.ball_query_multi_wrapper(1, n, m, [r for r, _ in sc], [ns for _, ns in sc], d_c, d_xyz, index, outs)
+        for (r, ns), got in zip(sc, outs):
+            want = oracle.ball_query(r, ns, xyz, centres)
+            np.testing.assert_array_equal(host(got), want)
+    hits = (np.linalg.norm(xyz[0][None] - centres[0][:, None], axis=-1) < 6.0).sum(1)
+    assert hits.min() > (512 if n >= 16384 else 256)                   # every ball overflows the longest list of its kernel
+
+
 def test_ball_query_indexed_and_direct_paths_agree(oracle):
     """epnet_ball_query (direct scan) and epnet_ball_query_ws (spatially indexed, caller scratch) are two
     entry points of the C ABI with bit-identical output; the workspace contract is checked too"""
