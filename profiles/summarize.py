@@ -56,7 +56,7 @@ def families(rows):
             elif "bq_index_kernel" in n:
                 fam = "scene_index"
             elif "bq_query_kernel" in n or "bq_query2_kernel" in n or "ball_query_kernel" in n:
-                fam = "ball_query " + re.search(r"(bq_query2?_kernel<[\d, ]+>|ball_query_kernel<\d+>)", n).group(1)
+                fam = "ball_query " + re.search(r"(bq_query2?_kernel<[\w, ]+>|ball_query_kernel<\d+>)", n).group(1)
             else:
                 fam = "torch: " + n[:60]
         out.append((fam, idx))
