@@ -284,10 +284,12 @@ __global__ __launch_bounds__(kIxThreads) void bq_index_kernel(int n, int np, con
         for (int i = 0; i < kIxPerThread; ++i) pos[i] = s_hist[code[i]] + rank[i];   // start of the cell + rank inside it
         // a quarter of the scene per round; the 256-thread variant at most 512 points (8 KB): with 26 KB of LDS in all it still finds
         // room on a CU that holds two 64 KB workgroups of a row gather -- at 34 KB it waited for the whole gather to drain (260 us)
-        const int quarter = kIxThreads == 256 ? min(np >> 2, 512) : np >> 2;  // a multiple of 64 (np is a power of two >= 2048)
+        // (a multiple of 64: np is a multiple of 256 here. A scene index has a power of two, three_nn's own index of a known set any
+        // multiple of 64 -- 2304, 2816, 3328, 3840 are not whole rounds of 512: the last round is shorter)
+        const int quarter = kIxThreads == 256 ? min(np >> 2, 512) : np >> 2;
         for (int h = 0; h * quarter < np; ++h) {
-            const int base = h * quarter;
-            for (int p = q; p < quarter; p += kIxThreads)   // padding rows: never inside a ball
+            const int base = h * quarter, len = min(quarter, np - base);
+            for (int p = q; p < len; p += kIxThreads)   // padding rows: never inside a ball
                 if (base + p >= n) s_stage[p] = make_float4(3.0e38f, 3.0e38f, 3.0e38f, __int_as_float(-1));
 #pragma unroll
             for (int i = 0; i < kIxPerThread; ++i) {
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(kIxThreads) void bq_index_kernel(int n, int np, con
                     s_stage[pos[i] - base] = make_float4(px[i], py[i], pz[i], __int_as_float(k));
             }
             __syncthreads();
-            for (int p = q; p < quarter; p += kIxThreads) {
+            for (int p = q; p < len; p += kIxThreads) {
                 const float4 v = s_stage[p];
                 sorted[base + p] = v;
                 bucket_box(base + p, v);

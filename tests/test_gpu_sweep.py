@@ -1,0 +1,180 @@
+"""A seeded sweep over the shapes BETWEEN the hand-picked parity cases: every sampling / query / interpolation entry point picks
+its kernel by size (one wave, register-resident, pruned over the scene index, big-scene, streaming; one or two centres per wave,
+bitmap or streaming hit lists; tile or per-unknown three_nn ...), so the cases below sit on and around those boundaries, with
+odd counts, m = 1, nsample = 1, lattice clouds full of equal distances, duplicated rows and single-cell clouds. Bit-exact against
+the oracle (indices, squared distances); float sums within 1e-5.
+
+The generator is seeded: the same cases every run (a failure names its case, which can be replayed alone with -k)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib_loaded(hiplib):
+    assert torch.cuda.is_available()
+    return hiplib
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def assert_scatter_sum(got, terms, flat, targets):
+    """got (b, c, targets) against the float64 scatter-add of terms (b, c, p) to targets flat (b, p). The order of a target's terms
+    is free (atomicAdd in the reference), so the bound is relative to the sum of magnitudes of its list, not to the result"""
+    b, c, _ = terms.shape
+    want = np.zeros((b, c, targets))
+    mag = np.zeros((b, c, targets))
+    for s_ in range(b):
+        np.add.at(want[s_].T, flat[s_], terms[s_].T.astype(np.float64))
+        np.add.at(mag[s_].T, flat[s_], np.abs(terms[s_].T).astype(np.float64))
+    err = np.abs(got.astype(np.float64) - want)
+    assert (err <= 2e-7 * mag + 1e-5 * np.maximum(1.0, np.abs(want))).all(), float(err.max())
+    return want
+
+
+KINDS = ("kitti", "ubox", "dup", "kitti_q", "lattice", "blob", "line")
+
+
+def cloud(kind, b, n, seed):
+    """(b, n, 3) float32. Beyond epnet_amd.synth's families: `lattice` = integer grid points in random order (exact distance ties
+    between distinct points everywhere), `blob` = everything inside one cell of any spatial index (1 cm), `line` = collinear"""
+    from epnet_amd import synth
+    rng = np.random.default_rng(seed)
+    if kind in synth.KINDS:
+        return synth.scenes(kind, b, n, seed=seed).numpy()
+    if kind == "lattice":
+        side = int(np.ceil(n ** (1.0 / 3.0))) + 1
+        g = np.stack(np.meshgrid(np.arange(side), np.arange(side), np.arange(side), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+        return np.stack([g[rng.permutation(len(g))[:n]] * np.float32(0.25) for _ in range(b)])
+    if kind == "blob":
+        return (rng.random((b, n, 3)) * 0.01 + np.array([3.0, -1.0, 20.0])).astype(np.float32)
+    if kind == "line":
+        t = rng.random((b, n, 1)) * 60.0
+        return (t * np.array([0.6, 0.0, 0.8]) + np.array([-10.0, 1.0, 0.0])).astype(np.float32)
+    raise ValueError(kind)
+
+
+# sizes on and around the kernel-selection boundaries
+_N_EDGES = (1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049, 4095, 4096,
+            4097, 8191, 8192, 8193, 16383, 16384, 16385, 20000, 32768, 32769, 65535, 65536, 65537, 70001)
+
+
+def _cases(count, seed, n_max, with_m=True):
+    rng = np.random.default_rng(seed)
+    edges = [n for n in _N_EDGES if n <= n_max]
+    out = []
+    for i in range(count):
+        n = int(edges[i % len(edges)]) if i < 2 * len(edges) else int(np.exp(rng.uniform(0, np.log(n_max))))
+        n = max(1, min(n, n_max))
+        b = int(rng.integers(1, 4)) if n <= 20000 else 1
+        m = int(min(n, max(1, np.exp(rng.uniform(0, np.log(max(2, min(n, 5000)))))))) if with_m else 0
+        out.append((i, b, n, m, KINDS[int(rng.integers(0, len(KINDS)))]))
+    return out
+
+
+@pytest.mark.parametrize("case,b,n,m,kind", _cases(96, 11, 70001))
+def test_sweep_furthest_point_sampling(oracle, case, b, n, m, kind):
+    from epnet_amd import pointnet2_cuda as ext
+    if n * m > 3.0e8:
+        m = max(1, int(3.0e8 // n))            # (keeps the oracle's O(n m) scan within seconds)
+    xyz = cloud(kind, b, n, seed=1000 + case)
+    d_xyz = dev(xyz)
+    want = oracle.furthest_point_sampling(xyz, m)
+    # the extension's own entry point (picks wave / register-resident / big-scene / streaming kernels by n) ...
+    temp = torch.full((b, n), 1e10, device=DEV)
+    idx = torch.full((b, m), -9, dtype=torch.int32, device=DEV)
+    ext.furthest_point_sampling_wrapper(b, n, m, d_xyz, temp, idx)
+    np.testing.assert_array_equal(host(idx), want)
+    # ... and the pruned kernels over a scene index, where one exists for this size
+    index = ext.scene_index(d_xyz)
+    if index is not None:
+        temp.fill_(1e10)
+        idx.fill_(-9)
+        ext.furthest_point_sampling_indexed_wrapper(b, n, m, d_xyz, index, temp, idx)
+        np.testing.assert_array_equal(host(idx), want)
+
+
+@pytest.mark.parametrize("case,b,n,m,kind", _cases(96, 12, 65536))
+@pytest.mark.parametrize("pair", ["0", "1"])
+def test_sweep_ball_query(oracle, case, b, n, m, kind, pair, monkeypatch):
+    from epnet_amd import pointnet2_utils as p2u
+    monkeypatch.setenv("EPNET_BQ_PAIR", pair)
+    rng = np.random.default_rng(5000 + case)
+    m = min(m, 600)
+    xyz = cloud(kind, b, n, seed=2000 + case)
+    extent = float(np.ptp(xyz[0], axis=0).max()) or 1.0
+    radius = float(np.exp(rng.uniform(np.log(extent / 300.0), np.log(extent * 1.5))))
+    ns = int(rng.choice([1, 2, 5, 16, 32, 63, 64, 65, 100]))
+    centres = np.ascontiguousarray(xyz[:, rng.permutation(n)[:m]] + (rng.random((b, m, 3)) < 0.3) * rng.normal(0, radius / 2, (b, m, 3))).astype(np.float32)
+    got = host(p2u.ball_query(radius, ns, dev(xyz), dev(centres)))
+    np.testing.assert_array_equal(got, oracle.ball_query(radius, ns, xyz, centres))
+
+
+@pytest.mark.parametrize("case,b,n,m,kind", _cases(64, 13, 40000))
+def test_sweep_three_nn_and_interpolation(oracle, case, b, n, m, kind):
+    """unknown set of n points, known set = m of them (an FP module's shapes) or an unrelated cloud"""
+    from epnet_amd import pointnet2_cuda as ext
+    rng = np.random.default_rng(7000 + case)
+    unknown = cloud(kind, b, n, seed=3000 + case)
+    if case % 3 == 0:
+        known = cloud(KINDS[case % len(KINDS)], b, m, seed=4000 + case)
+    else:
+        known = np.ascontiguousarray(unknown[:, rng.permutation(n)[:m]])
+    d2 = torch.full((b, n, 3), -1.0, device=DEV)
+    idx = torch.full((b, n, 3), -9, dtype=torch.int32, device=DEV)
+    ext.three_nn_wrapper(b, n, m, dev(unknown), dev(known), d2, idx)
+    o_d2, o_idx = oracle.three_nn(unknown, known)
+    np.testing.assert_array_equal(host(idx), o_idx)
+    np.testing.assert_array_equal(host(d2), o_d2)
+    c = int(rng.choice([1, 3, 4, 7, 32, 128]))
+    feats = rng.standard_normal((b, c, m)).astype(np.float32)
+    safe = np.clip(o_idx, 0, m - 1)                         # (m < 3: the reference leaves unset slots at index 0 already)
+    w = rng.random((b, n, 3)).astype(np.float32)
+    w /= w.sum(-1, keepdims=True)
+    out = torch.empty((b, c, n), device=DEV)
+    ext.three_interpolate_wrapper(b, c, m, n, dev(feats), dev(safe), dev(w), out)
+    np.testing.assert_array_equal(host(out), oracle.three_interpolate(feats, safe, w))
+    go = rng.standard_normal((b, c, n)).astype(np.float32)
+    grad = torch.zeros((b, c, m), device=DEV)
+    ext.three_interpolate_grad_wrapper(b, c, n, m, dev(go), dev(safe), dev(w), grad)
+    terms = (go[:, :, :, None] * w[:, None, :, :]).reshape(b, c, n * 3)          # (fp32 products, as the kernels form them)
+    want = assert_scatter_sum(host(grad), terms, safe.reshape(b, -1).astype(np.int64), m)
+    np.testing.assert_allclose(oracle.three_interpolate_grad(go, safe, w, m), want, rtol=1e-3, atol=1e-2 * max(1.0, n / m / 30.0))   # the oracle agrees with the yardstick
+
+
+@pytest.mark.parametrize("case,b,n,m,kind", _cases(64, 14, 20000))
+def test_sweep_grouping_and_gather(oracle, case, b, n, m, kind):
+    from epnet_amd import pointnet2_cuda as ext
+    rng = np.random.default_rng(9000 + case)
+    c = int(rng.choice([1, 3, 5, 16, 64, 96, 130]))
+    ns = int(rng.choice([1, 3, 16, 32, 64]))
+    m = min(m, 700)
+    feats = rng.standard_normal((b, c, n)).astype(np.float32)
+    idx = rng.integers(0, n, size=(b, m, ns)).astype(np.int32)
+    out = torch.empty((b, c, m, ns), device=DEV)
+    ext.group_points_wrapper(b, c, n, m, ns, dev(feats), dev(idx), out)
+    np.testing.assert_array_equal(host(out), oracle.group_points(feats, idx))
+    go = rng.standard_normal((b, c, m, ns)).astype(np.float32)
+    grad = torch.zeros((b, c, n), device=DEV)
+    ext.group_points_grad_wrapper(b, c, n, m, ns, dev(go), dev(idx), grad)
+    want = assert_scatter_sum(host(grad), go.reshape(b, c, -1), idx.reshape(b, -1).astype(np.int64), n)
+    np.testing.assert_allclose(oracle.group_points_grad(go, idx, n), want, rtol=1e-3, atol=1e-2 * max(1.0, m * ns / n / 30.0))
+    gi = rng.integers(0, n, size=(b, m)).astype(np.int32)
+    g_out = torch.empty((b, c, m), device=DEV)
+    ext.gather_points_wrapper(b, c, n, m, dev(feats), dev(gi), g_out)
+    np.testing.assert_array_equal(host(g_out), oracle.gather_points(feats, gi))
+    ggo = rng.standard_normal((b, c, m)).astype(np.float32)
+    ggrad = torch.zeros((b, c, n), device=DEV)
+    ext.gather_points_grad_wrapper(b, c, n, m, dev(ggo), dev(gi), ggrad)
+    want = assert_scatter_sum(host(ggrad), ggo, gi.astype(np.int64), n)
+    np.testing.assert_allclose(oracle.gather_points_grad(ggo, gi, n), want, rtol=1e-3, atol=1e-2 * max(1.0, m / n / 30.0))
