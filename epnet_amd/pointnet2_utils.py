@@ -151,7 +151,8 @@ def sample_pyramid(xyz: torch.Tensor, npoints):
     """the sampling of ALL set-abstraction levels up front: furthest point sampling depends on the
     coordinates only (pointnet2_modules.py:39-45), never on features, so the chain xyz -> npoints[0] -> npoints[1] -> ...
     (scene index, FPS, centres of every level) is issued on a side stream and runs beside the shared MLPs of the levels
-    above it instead of between them. Returns one ``(idx, new_xyz, event)`` per level for
+    above it instead of between them. Returns one ``(idx, new_xyz, event, index)`` per level (index: the scene index of the level's
+    input, or None) for
     ``_PointnetSAModuleBase.forward(..., presampled=...)``, which waits for the event; same values as the modules
     compute themselves."""
     assert xyz.is_cuda and xyz.is_contiguous()

@@ -178,3 +178,134 @@ def test_sweep_grouping_and_gather(oracle, case, b, n, m, kind):
     ext.gather_points_grad_wrapper(b, c, n, m, dev(ggo), dev(gi), ggrad)
     want = assert_scatter_sum(host(ggrad), ggo, gi.astype(np.int64), n)
     np.testing.assert_allclose(oracle.gather_points_grad(ggo, gi, n), want, rtol=1e-3, atol=1e-2 * max(1.0, m / n / 30.0))
+
+
+def _pyramids(count, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(count):
+        n = int(rng.choice([1024, 1025, 2048, 3000, 4096, 5000, 8192, 16384, 16385, 20000]))
+        levels = int(rng.integers(2, 5))
+        npoints, cur = [], n
+        for _ in range(levels):
+            cur = max(1, int(cur / float(rng.choice([1.0, 1.5, 2.0, 4.0, 7.3]))))
+            npoints.append(cur)
+        out.append((i, int(rng.integers(1, 4)), n, tuple(npoints), KINDS[int(rng.integers(0, len(KINDS)))]))
+    return out
+
+
+@pytest.mark.parametrize("case,b,n,npoints,kind", _pyramids(40, 15))
+def test_sweep_sampling_pyramid(oracle, case, b, n, npoints, kind):
+    """the chain of samplings of an SA pyramid (levels 2.. take the identity where the level above reports a tie-free prefix, replay
+    or run their rounds otherwise) on clouds with and without ties: every level bit-equal to furthest point sampling of the
+    level above's centres"""
+    from epnet_amd import pointnet2_utils as p2u
+    xyz = cloud(kind, b, n, seed=6000 + case)
+    levels = p2u.sample_pyramid(dev(xyz), list(npoints))
+    torch.cuda.synchronize()
+    cur = xyz
+    for (idx, new_xyz, _event, _index), m in zip(levels, npoints):
+        want = oracle.furthest_point_sampling(cur, m)
+        np.testing.assert_array_equal(host(idx), want)
+        cur = np.ascontiguousarray(np.take_along_axis(cur, want[..., None].astype(np.int64), axis=1))
+        np.testing.assert_array_equal(host(new_xyz), cur)
+
+
+@pytest.mark.parametrize("case,b,n,m,kind", _cases(48, 16, 20000))
+def test_sweep_query_and_group(oracle, case, b, n, m, kind):
+    """QueryAndGroup (ball query over a scene index + the fused [xyz - centre ; features] grouping) against the oracle's ball
+    query and grouping, composed as pointnet2_utils.py:249-257 composes them"""
+    from epnet_amd import pointnet2_utils as p2u
+    rng = np.random.default_rng(11000 + case)
+    m = min(m, 500)
+    c = int(rng.choice([0, 1, 3, 16, 19, 64, 96]))
+    ns = int(rng.choice([1, 4, 7, 16, 32, 64]))
+    use_xyz = bool(rng.integers(0, 2)) or c == 0
+    xyz = cloud(kind, b, n, seed=8000 + case)
+    extent = float(np.ptp(xyz[0], axis=0).max()) or 1.0
+    radius = float(np.exp(rng.uniform(np.log(extent / 100.0), np.log(extent))))
+    centres = np.ascontiguousarray(xyz[:, rng.permutation(n)[:m]])
+    feats = rng.standard_normal((b, c, n)).astype(np.float32) if c else None
+    got = p2u.QueryAndGroup(radius, ns, use_xyz=use_xyz)(dev(xyz), dev(centres), dev(feats) if c else None)
+    idx = oracle.ball_query(radius, ns, xyz, centres)
+    parts = []
+    if use_xyz:
+        parts.append(oracle.group_points(np.ascontiguousarray(xyz.transpose(0, 2, 1)), idx) - centres.transpose(0, 2, 1)[..., None])
+    if c:
+        parts.append(oracle.group_points(feats, idx))
+    np.testing.assert_array_equal(host(got), np.concatenate(parts, axis=1))
+
+
+@pytest.mark.parametrize("case,b,n,m,kind", _cases(40, 17, 40000))
+@pytest.mark.parametrize("tile", ["1", "1000000000"])
+def test_sweep_three_nn_over_scene_indices(oracle, case, b, n, m, kind, tile, monkeypatch):
+    """epnet_three_nn_indexed: a wave per bucket of unknowns (forced with EPNET_NN_TILE_MIN_BUCKETS=1) or per unknown, over the scene
+    indices of whichever of the two sets has one"""
+    from epnet_amd import pointnet2_cuda as ext
+    monkeypatch.setenv("EPNET_NN_TILE_MIN_BUCKETS", tile)
+    rng = np.random.default_rng(13000 + case)
+    m = max(m, int(rng.choice([1, 1024, 1100, 2259, 4096])))
+    unknown = cloud(kind, b, n, seed=9000 + case)
+    known = cloud(KINDS[(case + 2) % len(KINDS)], b, m, seed=9500 + case)
+    if m >= 8 and n >= 8:
+        known[:, :4] = unknown[:, :4]          # exact zero distances
+        known[:, 4:8] = known[:, :4]           # ... and ties between equal known rows
+    d_u, d_k = dev(unknown), dev(known)
+    o_d2, o_i = oracle.three_nn(unknown, known)
+    ui, ki = ext.scene_index(d_u), ext.scene_index(d_k)
+    d2 = torch.full((b, n, 3), -1.0, device=DEV)
+    i = torch.full((b, n, 3), -1, dtype=torch.int32, device=DEV)
+    ext.three_nn_indexed_wrapper(b, n, m, d_u, d_k, ui, ki, d2, i)
+    np.testing.assert_array_equal(host(i), o_i)
+    np.testing.assert_array_equal(host(d2), o_d2)
+
+
+def _pool_cases(count, seed):
+    rng = np.random.default_rng(seed)
+    return [(i, int(rng.integers(1, 4)), int(np.exp(rng.uniform(np.log(1), np.log(20000)))), int(rng.integers(1, 70)),
+             int(rng.choice([0, 1, 3, 16, 130])), int(rng.choice([1, 16, 33, 512, 600]))) for i in range(count)]
+
+
+@pytest.mark.parametrize("case,b,n,m,c,s", _pool_cases(32, 18))
+def test_sweep_roipool3d(oracle, case, b, n, m, c, s):
+    from epnet_amd import kitti_utils, roipool3d_cuda as ext, synth
+    pts = cloud("kitti", b, n, seed=12000 + case)
+    boxes = np.stack([synth.proposal_boxes(m, seed=12500 + case + i, num_objects=40, jitter=0.5)[0].numpy() for i in range(b)])
+    boxes = kitti_utils.enlarge_box3d(boxes.reshape(-1, 7), 0.2 * (case % 3)).reshape(b, m, 7)
+    feat = np.random.default_rng(case).standard_normal((b, n, c)).astype(np.float32)
+    out = torch.zeros((b, m, s, 3 + c), device=DEV)
+    flag = torch.zeros((b, m), dtype=torch.int32, device=DEV)
+    ext.forward(dev(pts), dev(boxes), dev(feat), out, flag)
+    o_pool, o_flag = oracle.roipool3d(pts, boxes, feat, s)
+    np.testing.assert_array_equal(host(flag), o_flag)
+    np.testing.assert_array_equal(host(out), o_pool)
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_sweep_nms_and_iou(oracle, case):
+    """axis-aligned NMS keep lists bit-exact; rotated overlap / IoU within 1e-5; rotated NMS with a threshold kept away from any
+    pair's IoU (the trigonometry may differ in the last bit)"""
+    from epnet_amd import iou3d_cuda as ext, kitti_utils, synth
+    rng = np.random.default_rng(14000 + case)
+    n = int(rng.choice([1, 2, 63, 64, 65, 300, 1000, 2049]))
+    bx, sc = synth.proposal_boxes(n, seed=14500 + case, num_objects=max(2, n // int(rng.choice([3, 20]))), jitter=float(rng.choice([0.2, 1.5])))
+    bev = kitti_utils.boxes3d_to_bev_torch(bx).numpy()
+    sorted_boxes = np.ascontiguousarray(bev[np.argsort(-sc.numpy(), kind="stable")])
+    thr = float(rng.choice([0.1, 0.5, 0.85]))
+    keep = torch.zeros((n,), dtype=torch.int64)
+    num = ext.nms_normal_gpu(dev(sorted_boxes), keep, thr)
+    o_keep = oracle.nms(sorted_boxes, thr, False)
+    assert num == len(o_keep)
+    np.testing.assert_array_equal(keep[:num].numpy(), o_keep)
+    nb = min(n, 400)
+    a, b_ = sorted_boxes[:nb], sorted_boxes[::-1][:max(1, nb // 3)].copy()
+    for fn, ofn in ((ext.boxes_overlap_bev_gpu, oracle.boxes_overlap_bev), (ext.boxes_iou_bev_gpu, oracle.boxes_iou_bev)):
+        ans = torch.zeros((a.shape[0], b_.shape[0]), device=DEV)
+        fn(dev(a), dev(b_), ans)
+        np.testing.assert_allclose(host(ans), ofn(a, b_), rtol=0, atol=1e-5)
+    small = sorted_boxes[:min(n, 700)]
+    full = oracle.boxes_iou_bev(small, small)
+    while np.abs(full - thr).min() < 1e-5:
+        thr += 0.0137
+    k2, n2 = ext.nms_device(dev(small), thr)
+    np.testing.assert_array_equal(host(k2[:int(n2.item())]), oracle.nms(small, thr, True))
