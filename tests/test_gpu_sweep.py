@@ -309,3 +309,52 @@ def test_sweep_nms_and_iou(oracle, case):
         thr += 0.0137
     k2, n2 = ext.nms_device(dev(small), thr)
     np.testing.assert_array_equal(host(k2[:int(n2.item())]), oracle.nms(small, thr, True))
+
+
+@pytest.mark.parametrize("case,b,n,m,kind", _cases(48, 19, 65536))
+@pytest.mark.parametrize("pair", ["0", "1"])
+def test_sweep_msg_level(oracle, case, b, n, m, kind, pair, monkeypatch):
+    """one MSG level as the SA stack issues it: the ball queries of all scales in one launch (centre order and the centres' own
+    spatial order), the groupings of all scales in one call, the neighbourhood max-pool -- 1 to 3 scales, nested or not"""
+    from epnet_amd import pointnet2_cuda as ext
+    monkeypatch.setenv("EPNET_BQ_PAIR", pair)
+    rng = np.random.default_rng(15000 + case)
+    if n < 1024:
+        n = int(rng.choice([1024, 1500, 2048, 2049]))          # (the multi-scale entry points take a scene index)
+    m = int(min(m, 400, n))
+    k = int(rng.integers(1, 4))
+    c = int(rng.choice([0, 4, 16, 19, 64]))
+    xyz = cloud(kind, b, n, seed=10000 + case)
+    extent = float(np.ptp(xyz[0], axis=0).max()) or 1.0
+    radii = [float(np.exp(rng.uniform(np.log(extent / 200.0), np.log(extent)))) for _ in range(k)]
+    nss = [int(rng.choice([1, 4, 8, 16, 32, 64, 72])) for _ in range(k)]
+    centres = np.ascontiguousarray(xyz[:, rng.permutation(n)[:m]])
+    d_xyz, d_c = dev(xyz), dev(centres)
+    index = ext.scene_index(d_xyz)
+    want = [oracle.ball_query(r, ns, xyz, centres) for r, ns in zip(radii, nss)]
+    outs = [torch.full((b, m, ns), -5, dtype=torch.int32, device=DEV) for ns in nss]
+    ext.ball_query_multi_wrapper(b, n, m, radii, nss, d_c, d_xyz, index, outs)
+    for got, w in zip(outs, want):
+        np.testing.assert_array_equal(host(got), w)
+    ci = ext.scene_index(d_c)                                     # None below 1024 centres: the wrapper falls back
+    outs2 = [torch.full((b, m, ns), -5, dtype=torch.int32, device=DEV) for ns in nss]
+    ext.ball_query_ordered_wrapper(b, n, m, radii, nss, d_c, d_xyz, index, ci, outs2)
+    for got, w in zip(outs2, want):
+        np.testing.assert_array_equal(host(got), w)
+    feats = rng.standard_normal((b, c, n)).astype(np.float32) if c else None
+    grouped = [torch.full((b, 3 + c, m, ns), float("nan"), device=DEV) for ns in nss]
+    ext.group_concat_multi_wrapper(b, c, n, m, nss, d_xyz, d_c, dev(feats) if c else None, outs, grouped, True)
+    xyz_t = np.ascontiguousarray(xyz.transpose(0, 2, 1))
+    for got, w in zip(grouped, want):
+        parts = [oracle.group_points(xyz_t, w) - centres.transpose(0, 2, 1)[..., None]]
+        if c:
+            parts.append(oracle.group_points(feats, w))
+        ref = np.concatenate(parts, axis=1)
+        np.testing.assert_array_equal(host(got), ref)
+        rows, ns = ref.shape[0] * ref.shape[1] * ref.shape[2], ref.shape[3]
+        pooled = torch.empty((rows,), device=DEV)
+        arg = torch.empty((rows,), dtype=torch.int32, device=DEV)
+        ext.pool_max_wrapper(rows, ns, got, pooled, arg)
+        o_max, o_arg = oracle.pool_max(ref)
+        np.testing.assert_array_equal(host(pooled), o_max.reshape(-1))
+        np.testing.assert_array_equal(host(arg), o_arg.reshape(-1))
