@@ -358,3 +358,58 @@ def test_sweep_msg_level(oracle, case, b, n, m, kind, pair, monkeypatch):
         o_max, o_arg = oracle.pool_max(ref)
         np.testing.assert_array_equal(host(pooled), o_max.reshape(-1))
         np.testing.assert_array_equal(host(arg), o_arg.reshape(-1))
+
+
+def _scene_cases(count, seed):
+    rng = np.random.default_rng(seed)
+    return [(i, int(rng.choice([5, 7, 8, 9, 15, 16, 17, 33, 64, 130])), int(rng.choice([64, 257, 1024, 1100, 2048, 4096])),
+             KINDS[int(rng.integers(0, len(KINDS)))]) for i in range(count)]
+
+
+@pytest.mark.parametrize("case,b,n,kind", _scene_cases(30, 20))
+def test_sweep_many_scenes(oracle, case, b, n, kind):
+    """scene counts that are no multiple of the 8 XCDs (every multi-workgroup kernel relabels its workgroups so that a scene's land
+    on one XCD: common.h xcd_scene_map, a bijection for ANY grid) through one SA level + its FP twin: sampling, ball query, fused
+    grouping, three_nn, interpolation and the gradients"""
+    from epnet_amd import pointnet2_cuda as ext, pointnet2_utils as p2u
+    rng = np.random.default_rng(17000 + case)
+    m = max(1, n // int(rng.choice([2, 4, 5])))
+    ns = int(rng.choice([4, 16, 32]))
+    c = int(rng.choice([4, 16, 33]))
+    xyz = cloud(kind, b, n, seed=16000 + case)
+    d_xyz = dev(xyz)
+    idx, centres = p2u.sample_and_gather(d_xyz, m)
+    o_idx = oracle.furthest_point_sampling(xyz, m)
+    np.testing.assert_array_equal(host(idx), o_idx)
+    o_centres = np.ascontiguousarray(np.take_along_axis(xyz, o_idx[..., None].astype(np.int64), axis=1))
+    np.testing.assert_array_equal(host(centres), o_centres)
+    extent = float(np.ptp(xyz[0], axis=0).max()) or 1.0
+    radius = extent / float(rng.choice([3.0, 10.0, 40.0]))
+    feats = rng.standard_normal((b, c, n)).astype(np.float32)
+    got = p2u.QueryAndGroup(radius, ns)(d_xyz, centres, dev(feats))
+    bq = oracle.ball_query(radius, ns, xyz, o_centres)
+    ref = np.concatenate([oracle.group_points(np.ascontiguousarray(xyz.transpose(0, 2, 1)), bq) - o_centres.transpose(0, 2, 1)[..., None],
+                          oracle.group_points(feats, bq)], axis=1)
+    np.testing.assert_array_equal(host(got), ref)
+    go = rng.standard_normal((b, c, m, ns)).astype(np.float32)
+    grad = torch.zeros((b, c, n), device=DEV)
+    ext.group_points_grad_wrapper(b, c, n, m, ns, dev(go), dev(bq), grad)
+    assert_scatter_sum(host(grad), go.reshape(b, c, -1), bq.reshape(b, -1).astype(np.int64), n)
+    # the FP twin: the n points are the unknown set, the m centres the known one
+    d2 = torch.empty((b, n, 3), device=DEV)
+    nn = torch.empty((b, n, 3), dtype=torch.int32, device=DEV)
+    ext.three_nn_wrapper(b, n, m, d_xyz, centres, d2, nn)
+    o_d2, o_nn = oracle.three_nn(xyz, o_centres)
+    np.testing.assert_array_equal(host(nn), o_nn)
+    np.testing.assert_array_equal(host(d2), o_d2)
+    safe = np.clip(o_nn, 0, m - 1)
+    w = rng.random((b, n, 3)).astype(np.float32)
+    w /= w.sum(-1, keepdims=True)
+    known_f = rng.standard_normal((b, c, m)).astype(np.float32)
+    out = torch.empty((b, c, n), device=DEV)
+    ext.three_interpolate_wrapper(b, c, m, n, dev(known_f), dev(safe), dev(w), out)
+    np.testing.assert_array_equal(host(out), oracle.three_interpolate(known_f, safe, w))
+    gi = rng.standard_normal((b, c, n)).astype(np.float32)
+    gk = torch.zeros((b, c, m), device=DEV)
+    ext.three_interpolate_grad_wrapper(b, c, n, m, dev(gi), dev(safe), dev(w), gk)
+    assert_scatter_sum(host(gk), (gi[:, :, :, None] * w[:, None, :, :]).reshape(b, c, n * 3), safe.reshape(b, -1).astype(np.int64), m)
