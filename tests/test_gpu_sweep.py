@@ -413,3 +413,47 @@ def test_sweep_many_scenes(oracle, case, b, n, kind):
     gk = torch.zeros((b, c, m), device=DEV)
     ext.three_interpolate_grad_wrapper(b, c, n, m, dev(gi), dev(safe), dev(w), gk)
     assert_scatter_sum(host(gk), (gi[:, :, :, None] * w[:, None, :, :]).reshape(b, c, n * 3), safe.reshape(b, -1).astype(np.int64), m)
+
+
+def _stack_cases(count, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(count):
+        n = int(rng.choice([2048, 3000, 4096, 8192, 16384, 20000]))
+        levels = int(rng.integers(1, 5))
+        npoints, radii, nsamples, chans, cur = [], [], [], [], n
+        for lvl in range(levels):
+            cur = max(8, cur // int(rng.choice([2, 4, 5])))
+            k = int(rng.integers(1, 3))
+            r0 = float(rng.choice([0.2, 0.5, 1.0])) * (lvl + 1)
+            npoints.append(cur)
+            radii.append(tuple(r0 * (j + 1) for j in range(k)))
+            nsamples.append(tuple(int(rng.choice([4, 16, 32, 64])) for _ in range(k)))
+            chans.append(0 if lvl == 0 and rng.integers(0, 2) else int(rng.choice([4, 16, 32, 96])))
+        mode = ("plain", "two", "three")[i % 3]
+        out.append((i, int(rng.integers(1, 4)), n, tuple(npoints), tuple(radii), tuple(nsamples), tuple(chans), mode))
+    return out
+
+
+@pytest.mark.parametrize("case,b,n,npoints,radii,nsamples,chans,mode", _stack_cases(12, 21))
+def test_sweep_sa_stack_configurations(oracle, case, b, n, npoints, radii, nsamples, chans, mode):
+    """the bench's product path (epnet_amd/sa_stack.py: HIP graphs, one / two / three stages) on pyramids other than the RPN's:
+    1 - 4 levels, one or two scales, 2048 - 20000 points, a stream of different batches; every tensor of every scene checked
+    by bench.verify_scene against the oracle"""
+    import bench
+    from epnet_amd import sa_stack
+    kinds = ("kitti", "dup", "ubox", "kitti_q", "lattice")
+    batches = [dev(cloud(kinds[(case + j) % len(kinds)], b, n, seed=18000 + 10 * case + j)) for j in range(4)]
+    stack = sa_stack.SAStack(b, n=n, device=DEV, npoints=npoints, radii=radii, nsamples=nsamples, feat_channels=chans, seed=case,
+                             pipelined=mode != "plain", fused_sampling=True, stages=3 if mode == "three" else None)
+    stack.capture(batches[0])
+    lag = {"plain": 0, "two": 1, "three": 2}[mode]
+    for k in range(len(batches)):
+        stack.replay(batches[k])
+        torch.cuda.synchronize()
+        if k < lag:
+            continue
+        for scene in range(b):
+            bad = bench.verify_scene(stack, batches[k], scene, prev_xyz=batches[k - 1] if lag >= 1 else None,
+                                     prev2_xyz=batches[k - 2] if lag >= 2 else None)
+            assert bad == [], (mode, k, scene, bad)
