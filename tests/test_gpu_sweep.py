@@ -28,6 +28,70 @@ def host(t):
     return t.detach().cpu().numpy()
 
 
+_GUARD = 4096          # bytes of canary on either side (a multiple of every alignment the library asks for)
+_CANARY = 0xA5
+
+
+class _GuardedAlloc:
+    """what the extension stand-ins and the operator layer allocate themselves -- scratch, scene indices, outputs -- with a canary
+    on either side: a kernel that writes past an allocation (or before it) fails the test it runs in even when the stray bytes
+    would have landed in somebody else's live memory unnoticed"""
+
+    def __init__(self):
+        self.live = []
+
+    def alloc(self, shape, dtype, device, zero=False):
+        shape = tuple(int(v) for v in (shape if isinstance(shape, (tuple, list, torch.Size)) else (shape,)))
+        nbytes = int(np.prod(shape, dtype=np.int64)) * torch.empty((), dtype=dtype).element_size()
+        pad = (-nbytes) % 16
+        raw = torch.full((_GUARD + nbytes + pad + _GUARD,), _CANARY, dtype=torch.uint8, device=device)
+        self.live.append((raw, nbytes, shape, dtype))
+        body = raw[_GUARD:_GUARD + nbytes].view(dtype).view(shape)
+        if zero:
+            body.zero_()
+        return body
+
+    def check(self):
+        for raw, nbytes, shape, dtype in self.live:
+            head, tail = raw[:_GUARD], raw[_GUARD + nbytes:]
+            assert bool((head == _CANARY).all()), ("bytes written BEFORE an allocation", shape, dtype)
+            assert bool((tail == _CANARY).all()), ("bytes written PAST an allocation", shape, dtype, int((tail != _CANARY).nonzero()[0]))
+        self.live.clear()
+
+
+@pytest.fixture(autouse=True)
+def guarded_allocations(monkeypatch):
+    from epnet_amd import pointnet2_cuda as ext, pointnet2_utils as p2u
+    g = _GuardedAlloc()
+
+    class _TorchProxy:          # pointnet2_cuda's `torch.empty(...)` for scratch and indices; everything else passes through
+        def __getattr__(self, name):
+            return getattr(torch, name)
+
+        @staticmethod
+        def empty(shape, dtype=torch.float32, device=None, **kw):
+            return g.alloc(shape, dtype, device) if device is not None and torch.device(device).type == "cuda" else torch.empty(shape, dtype=dtype, device=device, **kw)
+
+    monkeypatch.setattr(ext, "torch", _TorchProxy())
+    monkeypatch.setattr(p2u, "_new", lambda like, shape, dtype=torch.float32, zero=False: g.alloc(shape, dtype, like.device, zero))
+    _CURRENT.append(g)
+    yield g
+    _CURRENT.pop()
+    torch.cuda.synchronize()
+    g.check()
+
+
+_CURRENT = []
+
+
+def out_tensor(shape, dtype=torch.float32, fill=None):
+    """an output tensor of a direct wrapper call, guarded like the library's own allocations"""
+    t = _CURRENT[-1].alloc(shape, dtype, DEV)
+    if fill is not None:
+        t.fill_(fill)
+    return t
+
+
 def assert_scatter_sum(got, terms, flat, targets):
     """got (b, c, targets) against the float64 scatter-add of terms (b, c, p) to targets flat (b, p). The order of a target's terms
     is free (atomicAdd in the reference), so the bound is relative to the sum of magnitudes of its list, not to the result"""
@@ -91,8 +155,8 @@ def test_sweep_furthest_point_sampling(oracle, case, b, n, m, kind):
     d_xyz = dev(xyz)
     want = oracle.furthest_point_sampling(xyz, m)
     # the extension's own entry point (picks wave / register-resident / big-scene / streaming kernels by n) ...
-    temp = torch.full((b, n), 1e10, device=DEV)
-    idx = torch.full((b, m), -9, dtype=torch.int32, device=DEV)
+    temp = out_tensor((b, n), torch.float32, 1e10)
+    idx = out_tensor((b, m), torch.int32, -9)
     ext.furthest_point_sampling_wrapper(b, n, m, d_xyz, temp, idx)
     np.testing.assert_array_equal(host(idx), want)
     # ... and the pruned kernels over a scene index, where one exists for this size
@@ -130,8 +194,8 @@ def test_sweep_three_nn_and_interpolation(oracle, case, b, n, m, kind):
         known = cloud(KINDS[case % len(KINDS)], b, m, seed=4000 + case)
     else:
         known = np.ascontiguousarray(unknown[:, rng.permutation(n)[:m]])
-    d2 = torch.full((b, n, 3), -1.0, device=DEV)
-    idx = torch.full((b, n, 3), -9, dtype=torch.int32, device=DEV)
+    d2 = out_tensor((b, n, 3), torch.float32, -1.0)
+    idx = out_tensor((b, n, 3), torch.int32, -9)
     ext.three_nn_wrapper(b, n, m, dev(unknown), dev(known), d2, idx)
     o_d2, o_idx = oracle.three_nn(unknown, known)
     np.testing.assert_array_equal(host(idx), o_idx)
@@ -141,11 +205,11 @@ def test_sweep_three_nn_and_interpolation(oracle, case, b, n, m, kind):
     safe = np.clip(o_idx, 0, m - 1)                         # (m < 3: the reference leaves unset slots at index 0 already)
     w = rng.random((b, n, 3)).astype(np.float32)
     w /= w.sum(-1, keepdims=True)
-    out = torch.empty((b, c, n), device=DEV)
+    out = out_tensor((b, c, n))
     ext.three_interpolate_wrapper(b, c, m, n, dev(feats), dev(safe), dev(w), out)
     np.testing.assert_array_equal(host(out), oracle.three_interpolate(feats, safe, w))
     go = rng.standard_normal((b, c, n)).astype(np.float32)
-    grad = torch.zeros((b, c, m), device=DEV)
+    grad = out_tensor((b, c, m), torch.float32, 0)
     ext.three_interpolate_grad_wrapper(b, c, n, m, dev(go), dev(safe), dev(w), grad)
     terms = (go[:, :, :, None] * w[:, None, :, :]).reshape(b, c, n * 3)          # (fp32 products, as the kernels form them)
     want = assert_scatter_sum(host(grad), terms, safe.reshape(b, -1).astype(np.int64), m)
@@ -161,20 +225,20 @@ def test_sweep_grouping_and_gather(oracle, case, b, n, m, kind):
     m = min(m, 700)
     feats = rng.standard_normal((b, c, n)).astype(np.float32)
     idx = rng.integers(0, n, size=(b, m, ns)).astype(np.int32)
-    out = torch.empty((b, c, m, ns), device=DEV)
+    out = out_tensor((b, c, m, ns))
     ext.group_points_wrapper(b, c, n, m, ns, dev(feats), dev(idx), out)
     np.testing.assert_array_equal(host(out), oracle.group_points(feats, idx))
     go = rng.standard_normal((b, c, m, ns)).astype(np.float32)
-    grad = torch.zeros((b, c, n), device=DEV)
+    grad = out_tensor((b, c, n), torch.float32, 0)
     ext.group_points_grad_wrapper(b, c, n, m, ns, dev(go), dev(idx), grad)
     want = assert_scatter_sum(host(grad), go.reshape(b, c, -1), idx.reshape(b, -1).astype(np.int64), n)
     np.testing.assert_allclose(oracle.group_points_grad(go, idx, n), want, rtol=1e-3, atol=1e-2 * max(1.0, m * ns / n / 30.0))
     gi = rng.integers(0, n, size=(b, m)).astype(np.int32)
-    g_out = torch.empty((b, c, m), device=DEV)
+    g_out = out_tensor((b, c, m))
     ext.gather_points_wrapper(b, c, n, m, dev(feats), dev(gi), g_out)
     np.testing.assert_array_equal(host(g_out), oracle.gather_points(feats, gi))
     ggo = rng.standard_normal((b, c, m)).astype(np.float32)
-    ggrad = torch.zeros((b, c, n), device=DEV)
+    ggrad = out_tensor((b, c, n), torch.float32, 0)
     ext.gather_points_grad_wrapper(b, c, n, m, dev(ggo), dev(gi), ggrad)
     want = assert_scatter_sum(host(ggrad), ggo, gi.astype(np.int64), n)
     np.testing.assert_allclose(oracle.gather_points_grad(ggo, gi, n), want, rtol=1e-3, atol=1e-2 * max(1.0, m / n / 30.0))
@@ -253,8 +317,8 @@ def test_sweep_three_nn_over_scene_indices(oracle, case, b, n, m, kind, tile, mo
     d_u, d_k = dev(unknown), dev(known)
     o_d2, o_i = oracle.three_nn(unknown, known)
     ui, ki = ext.scene_index(d_u), ext.scene_index(d_k)
-    d2 = torch.full((b, n, 3), -1.0, device=DEV)
-    i = torch.full((b, n, 3), -1, dtype=torch.int32, device=DEV)
+    d2 = out_tensor((b, n, 3), torch.float32, -1.0)
+    i = out_tensor((b, n, 3), torch.int32, -1)
     ext.three_nn_indexed_wrapper(b, n, m, d_u, d_k, ui, ki, d2, i)
     np.testing.assert_array_equal(host(i), o_i)
     np.testing.assert_array_equal(host(d2), o_d2)
@@ -273,8 +337,8 @@ def test_sweep_roipool3d(oracle, case, b, n, m, c, s):
     boxes = np.stack([synth.proposal_boxes(m, seed=12500 + case + i, num_objects=40, jitter=0.5)[0].numpy() for i in range(b)])
     boxes = kitti_utils.enlarge_box3d(boxes.reshape(-1, 7), 0.2 * (case % 3)).reshape(b, m, 7)
     feat = np.random.default_rng(case).standard_normal((b, n, c)).astype(np.float32)
-    out = torch.zeros((b, m, s, 3 + c), device=DEV)
-    flag = torch.zeros((b, m), dtype=torch.int32, device=DEV)
+    out = out_tensor((b, m, s, 3 + c), torch.float32, 0)
+    flag = out_tensor((b, m), torch.int32, 0)
     ext.forward(dev(pts), dev(boxes), dev(feat), out, flag)
     o_pool, o_flag = oracle.roipool3d(pts, boxes, feat, s)
     np.testing.assert_array_equal(host(flag), o_flag)
@@ -300,7 +364,7 @@ def test_sweep_nms_and_iou(oracle, case):
     nb = min(n, 400)
     a, b_ = sorted_boxes[:nb], sorted_boxes[::-1][:max(1, nb // 3)].copy()
     for fn, ofn in ((ext.boxes_overlap_bev_gpu, oracle.boxes_overlap_bev), (ext.boxes_iou_bev_gpu, oracle.boxes_iou_bev)):
-        ans = torch.zeros((a.shape[0], b_.shape[0]), device=DEV)
+        ans = out_tensor((a.shape[0], b_.shape[0]), torch.float32, 0)
         fn(dev(a), dev(b_), ans)
         np.testing.assert_allclose(host(ans), ofn(a, b_), rtol=0, atol=1e-5)
     small = sorted_boxes[:min(n, 700)]
@@ -332,17 +396,17 @@ def test_sweep_msg_level(oracle, case, b, n, m, kind, pair, monkeypatch):
     d_xyz, d_c = dev(xyz), dev(centres)
     index = ext.scene_index(d_xyz)
     want = [oracle.ball_query(r, ns, xyz, centres) for r, ns in zip(radii, nss)]
-    outs = [torch.full((b, m, ns), -5, dtype=torch.int32, device=DEV) for ns in nss]
+    outs = [out_tensor((b, m, ns), torch.int32, -5) for ns in nss]
     ext.ball_query_multi_wrapper(b, n, m, radii, nss, d_c, d_xyz, index, outs)
     for got, w in zip(outs, want):
         np.testing.assert_array_equal(host(got), w)
     ci = ext.scene_index(d_c)                                     # None below 1024 centres: the wrapper falls back
-    outs2 = [torch.full((b, m, ns), -5, dtype=torch.int32, device=DEV) for ns in nss]
+    outs2 = [out_tensor((b, m, ns), torch.int32, -5) for ns in nss]
     ext.ball_query_ordered_wrapper(b, n, m, radii, nss, d_c, d_xyz, index, ci, outs2)
     for got, w in zip(outs2, want):
         np.testing.assert_array_equal(host(got), w)
     feats = rng.standard_normal((b, c, n)).astype(np.float32) if c else None
-    grouped = [torch.full((b, 3 + c, m, ns), float("nan"), device=DEV) for ns in nss]
+    grouped = [out_tensor((b, 3 + c, m, ns), torch.float32, float("nan")) for ns in nss]
     ext.group_concat_multi_wrapper(b, c, n, m, nss, d_xyz, d_c, dev(feats) if c else None, outs, grouped, True)
     xyz_t = np.ascontiguousarray(xyz.transpose(0, 2, 1))
     for got, w in zip(grouped, want):
@@ -352,8 +416,8 @@ def test_sweep_msg_level(oracle, case, b, n, m, kind, pair, monkeypatch):
         ref = np.concatenate(parts, axis=1)
         np.testing.assert_array_equal(host(got), ref)
         rows, ns = ref.shape[0] * ref.shape[1] * ref.shape[2], ref.shape[3]
-        pooled = torch.empty((rows,), device=DEV)
-        arg = torch.empty((rows,), dtype=torch.int32, device=DEV)
+        pooled = out_tensor((rows,))
+        arg = out_tensor((rows,), torch.int32)
         ext.pool_max_wrapper(rows, ns, got, pooled, arg)
         o_max, o_arg = oracle.pool_max(ref)
         np.testing.assert_array_equal(host(pooled), o_max.reshape(-1))
@@ -392,12 +456,12 @@ def test_sweep_many_scenes(oracle, case, b, n, kind):
                           oracle.group_points(feats, bq)], axis=1)
     np.testing.assert_array_equal(host(got), ref)
     go = rng.standard_normal((b, c, m, ns)).astype(np.float32)
-    grad = torch.zeros((b, c, n), device=DEV)
+    grad = out_tensor((b, c, n), torch.float32, 0)
     ext.group_points_grad_wrapper(b, c, n, m, ns, dev(go), dev(bq), grad)
     assert_scatter_sum(host(grad), go.reshape(b, c, -1), bq.reshape(b, -1).astype(np.int64), n)
     # the FP twin: the n points are the unknown set, the m centres the known one
-    d2 = torch.empty((b, n, 3), device=DEV)
-    nn = torch.empty((b, n, 3), dtype=torch.int32, device=DEV)
+    d2 = out_tensor((b, n, 3))
+    nn = out_tensor((b, n, 3), torch.int32)
     ext.three_nn_wrapper(b, n, m, d_xyz, centres, d2, nn)
     o_d2, o_nn = oracle.three_nn(xyz, o_centres)
     np.testing.assert_array_equal(host(nn), o_nn)
@@ -406,11 +470,11 @@ def test_sweep_many_scenes(oracle, case, b, n, kind):
     w = rng.random((b, n, 3)).astype(np.float32)
     w /= w.sum(-1, keepdims=True)
     known_f = rng.standard_normal((b, c, m)).astype(np.float32)
-    out = torch.empty((b, c, n), device=DEV)
+    out = out_tensor((b, c, n))
     ext.three_interpolate_wrapper(b, c, m, n, dev(known_f), dev(safe), dev(w), out)
     np.testing.assert_array_equal(host(out), oracle.three_interpolate(known_f, safe, w))
     gi = rng.standard_normal((b, c, n)).astype(np.float32)
-    gk = torch.zeros((b, c, m), device=DEV)
+    gk = out_tensor((b, c, m), torch.float32, 0)
     ext.three_interpolate_grad_wrapper(b, c, n, m, dev(gi), dev(safe), dev(w), gk)
     assert_scatter_sum(host(gk), (gi[:, :, :, None] * w[:, None, :, :]).reshape(b, c, n * 3), safe.reshape(b, -1).astype(np.int64), m)
 
