@@ -521,3 +521,72 @@ def test_sweep_sa_stack_configurations(oracle, case, b, n, npoints, radii, nsamp
             bad = bench.verify_scene(stack, batches[k], scene, prev_xyz=batches[k - 1] if lag >= 1 else None,
                                      prev2_xyz=batches[k - 2] if lag >= 2 else None)
             assert bad == [], (mode, k, scene, bad)
+
+
+def _linear_cases(count, seed):
+    rng = np.random.default_rng(seed)
+    return [(i, int(rng.integers(1, 4)), int(rng.choice([1, 3, 5, 8, 16, 33, 64, 96, 128, 130])), int(np.exp(rng.uniform(np.log(8), np.log(20000)))),
+             int(rng.choice([1, 7, 64, 200, 1024])), int(rng.choice([1, 3, 4, 16, 32, 64])), bool(rng.integers(0, 2))) for i in range(count)]
+
+
+@pytest.mark.parametrize("case,b,c,n,m,ns,bias", _linear_cases(40, 22))
+def test_sweep_group_linear(oracle, case, b, c, n, m, ns, bias):
+    """the first shared-MLP layer folded into the grouping (epnet_group_linear) and its weight gradient, against the oracle's
+    restatement (exact) and a float64 evaluation of the weight gradient"""
+    from epnet_amd import pointnet2_cuda as ext, pointnet2_utils as p2u
+    rng = np.random.default_rng(19000 + case)
+    m = min(m, n)
+    xyz = cloud(KINDS[case % len(KINDS)], b, n, seed=19500 + case)
+    new_xyz = np.ascontiguousarray(xyz[:, rng.permutation(n)[:m]])
+    z = rng.standard_normal((b, c, n)).astype(np.float32)
+    idx = rng.integers(0, n, size=(b, m, ns)).astype(np.int32)
+    w_xyz = (rng.standard_normal((c, 3)) * 0.3).astype(np.float32)
+    bv = rng.standard_normal((c,)).astype(np.float32) if bias else None
+    got = p2u.group_linear(dev(xyz), dev(new_xyz), dev(z), dev(idx), dev(w_xyz), None if bv is None else dev(bv))
+    np.testing.assert_array_equal(host(got), oracle.group_linear(xyz, new_xyz, z, idx, w_xyz, bv))
+    go = rng.standard_normal((b, c, m, ns)).astype(np.float32)
+    gw = out_tensor((c, 3), torch.float32, 0)
+    ext.group_linear_grad_w_wrapper(b, c, n, m, ns, dev(go), dev(xyz), dev(new_xyz), dev(idx), gw)
+    rel = xyz.astype(np.float64)[np.arange(b)[:, None, None], idx.astype(np.int64)] - new_xyz[:, :, None, :].astype(np.float64)   # (b, m, ns, 3)
+    want = np.einsum("bcms,bmsk->ck", go.astype(np.float64), rel)
+    mag = np.einsum("bcms,bmsk->ck", np.abs(go).astype(np.float64), np.abs(rel))
+    assert (np.abs(host(gw) - want) <= 3e-7 * mag + 1e-5).all()
+
+
+def _gather_cases(count, seed):
+    rng = np.random.default_rng(seed)
+    return [(i, int(rng.integers(1, 4)), int(rng.choice([1, 3, 5, 32, 64, 129, 256])), int(rng.choice([1, 2, 7, 24, 96])), int(rng.choice([1, 3, 9, 80, 320])),
+             int(np.exp(rng.uniform(0, np.log(16384)))), bool(rng.integers(0, 2))) for i in range(count)]
+
+
+@pytest.mark.parametrize("case,b,c,h,w,n,align", _gather_cases(40, 23))
+def test_sweep_feature_gather(case, b, c, h, w, n, align):
+    """the LI-Fusion point-to-pixel sampler against the op the reference calls (grid_sample, bilinear, zero padding), forward and the
+    gradient w.r.t. the feature map, with the torch.gather of the coordinates over sampled indices folded in on odd cases"""
+    import torch.nn.functional as F
+    from epnet_amd.li_fusion import Feature_Gather
+    g = torch.Generator().manual_seed(20000 + case)
+    fmap = torch.randn((b, c, h, w), generator=g)
+    n_src = n * 2 if case % 2 else n
+    xy_src = torch.rand((b, n_src, 2), generator=g) * 2.6 - 1.3
+    if case % 2:
+        idx = torch.stack([torch.randperm(n_src, generator=g)[:n] for _ in range(b)]).to(torch.int32)
+        xy = torch.gather(xy_src, 1, idx.long().unsqueeze(-1).expand(-1, -1, 2))
+    else:
+        idx, xy = None, xy_src
+    want = F.grid_sample(fmap, xy.unsqueeze(1), mode="bilinear", padding_mode="zeros", align_corners=align).squeeze(2)   # the stock op, fp32, CPU
+    fm = fmap.cuda().requires_grad_(True)
+    got = Feature_Gather(fm, xy_src.cuda(), align_corners=align) if idx is None else Feature_Gather(fm, xy_src.cuda(), align_corners=align, idx=idx.cuda())
+    if isinstance(got, tuple):
+        got = got[0]
+    # (as tests/test_li_fusion.py: align_corners=True agrees to 1e-5; with False the pixel coordinate carries one more rounding of a
+    # value ~W between a fused and an unfused evaluation)
+    tol = 1e-5 if align else 1e-4
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want.numpy(), rtol=tol, atol=tol)
+    gr = torch.randn((b, c, n), generator=g)
+    got_g, = torch.autograd.grad(got, fm, gr.cuda())
+    f64 = fmap.double().requires_grad_(True)
+    ref = F.grid_sample(f64, xy.double().unsqueeze(1), mode="bilinear", padding_mode="zeros", align_corners=align).squeeze(2)
+    want_g, = torch.autograd.grad(ref, f64, gr.double())
+    scale = max(1.0, float(want_g.abs().max()))
+    np.testing.assert_allclose(got_g.cpu().numpy(), want_g.numpy(), rtol=1e-4, atol=(1e-4 if align else 1e-3) * scale)
