@@ -1,5 +1,8 @@
+"""CPU simulation of the bucket pruning of furthest point sampling (design study of round 1: how many buckets a round touches for a
+given bucket size). Test-side tooling: it takes the sample sequence from the oracle, so it lives under tests/ (only tests, smoke() and
+bench.py's baseline / verification legs use oracle/)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from epnet_amd import synth
 from oracle import oracle
