@@ -590,3 +590,36 @@ def test_sweep_feature_gather(case, b, c, h, w, n, align):
     want_g, = torch.autograd.grad(ref, f64, gr.double())
     scale = max(1.0, float(want_g.abs().max()))
     np.testing.assert_allclose(got_g.cpu().numpy(), want_g.numpy(), rtol=1e-4, atol=(1e-4 if align else 1e-3) * scale)
+
+
+def _proposal_cases(count, seed):
+    rng = np.random.default_rng(seed)
+    # (distance-based only: the score-based path of the reference always takes the ROTATED NMS, :137, whose keep lists are held to
+    # thresholds away from borderline pairs in tests/test_proposal_layer.py; the axis-aligned one below is bit-exact everywhere)
+    return [(i, int(rng.integers(1, 4)), int(np.exp(rng.uniform(np.log(1), np.log(16384)))), True,
+             int(rng.choice([1, 7, 64, 65, 1000, 6300, 9000])), int(rng.choice([1, 4, 100, 512, 900])), float(rng.choice([0.05, 0.5, 0.85]))) for i in range(count)]
+
+
+@pytest.mark.parametrize("case,b,n,dist_based,pre,post,thresh", _proposal_cases(32, 24))
+def test_sweep_rpn_proposals(oracle, case, b, n, dist_based, pre, post, thresh):
+    """the fused proposal layer (score order -> distance bins -> axis-aligned NMS -> fixed-size outputs, no host sync) against the
+    oracle's scene-by-scene restatement of the reference loop (lib/rpn/proposal_layer.py:40-119): identical rows, scores, counts"""
+    from epnet_amd import iou3d_cuda, synth
+    g = torch.Generator().manual_seed(21000 + case)
+    xyz = synth.scenes("kitti", b, max(n, 2), seed=21500 + case)[:, :n]
+    boxes = torch.zeros((b, n, 7))
+    boxes[:, :, 0:3] = xyz + (torch.rand((b, n, 3), generator=g) - 0.5) * torch.tensor([2.0, 0.2, 2.0])
+    boxes[:, :, 3:6] = torch.tensor([1.5, 1.6, 3.9]) * (0.8 + 0.4 * torch.rand((b, n, 3), generator=g))
+    boxes[:, :, 6] = (torch.rand((b, n), generator=g) - 0.5) * 6
+    if case % 5 == 0:
+        boxes[:, :, 2] = boxes[:, :, 2] * 0.5 + 41          # the near bin empty
+    scores = torch.randn((b, n), generator=g)
+    order = torch.sort(scores, dim=1, descending=True)[1]
+    want_b, want_s, want_c = oracle.rpn_proposals(boxes.numpy(), scores.numpy(), order.numpy(), dist_based, pre, post, thresh, False)
+    rb = out_tensor((b, post, 7), torch.float32, float("nan"))
+    rs = out_tensor((b, post), torch.float32, float("nan"))
+    rc = out_tensor((b,), torch.int32, -1)
+    iou3d_cuda.rpn_proposals_gpu(boxes.to(DEV), scores.to(DEV), order.to(DEV), dist_based, pre, post, thresh, False, rb, rs, rc)
+    np.testing.assert_array_equal(host(rc), want_c)
+    np.testing.assert_array_equal(host(rs), want_s)
+    np.testing.assert_array_equal(host(rb), want_b)
