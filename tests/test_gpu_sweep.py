@@ -28,52 +28,11 @@ def host(t):
     return t.detach().cpu().numpy()
 
 
-_GUARD = 4096          # bytes of canary on either side (a multiple of every alignment the library asks for)
-_CANARY = 0xA5
-
-
-class _GuardedAlloc:
-    """what the extension stand-ins and the operator layer allocate themselves -- scratch, scene indices, outputs -- with a canary
-    on either side: a kernel that writes past an allocation (or before it) fails the test it runs in even when the stray bytes
-    would have landed in somebody else's live memory unnoticed"""
-
-    def __init__(self):
-        self.live = []
-
-    def alloc(self, shape, dtype, device, zero=False):
-        shape = tuple(int(v) for v in (shape if isinstance(shape, (tuple, list, torch.Size)) else (shape,)))
-        nbytes = int(np.prod(shape, dtype=np.int64)) * torch.empty((), dtype=dtype).element_size()
-        pad = (-nbytes) % 16
-        raw = torch.full((_GUARD + nbytes + pad + _GUARD,), _CANARY, dtype=torch.uint8, device=device)
-        self.live.append((raw, nbytes, shape, dtype))
-        body = raw[_GUARD:_GUARD + nbytes].view(dtype).view(shape)
-        if zero:
-            body.zero_()
-        return body
-
-    def check(self):
-        for raw, nbytes, shape, dtype in self.live:
-            head, tail = raw[:_GUARD], raw[_GUARD + nbytes:]
-            assert bool((head == _CANARY).all()), ("bytes written BEFORE an allocation", shape, dtype)
-            assert bool((tail == _CANARY).all()), ("bytes written PAST an allocation", shape, dtype, int((tail != _CANARY).nonzero()[0]))
-        self.live.clear()
-
-
 @pytest.fixture(autouse=True)
 def guarded_allocations(monkeypatch):
-    from epnet_amd import pointnet2_cuda as ext, pointnet2_utils as p2u
-    g = _GuardedAlloc()
-
-    class _TorchProxy:          # pointnet2_cuda's `torch.empty(...)` for scratch and indices; everything else passes through
-        def __getattr__(self, name):
-            return getattr(torch, name)
-
-        @staticmethod
-        def empty(shape, dtype=torch.float32, device=None, **kw):
-            return g.alloc(shape, dtype, device) if device is not None and torch.device(device).type == "cuda" else torch.empty(shape, dtype=dtype, device=device, **kw)
-
-    monkeypatch.setattr(ext, "torch", _TorchProxy())
-    monkeypatch.setattr(p2u, "_new", lambda like, shape, dtype=torch.float32, zero=False: g.alloc(shape, dtype, like.device, zero))
+    """canaries around everything the wrappers / the operator layer allocate and around the outputs below (conftest.GuardedAlloc)"""
+    from conftest import install_guards
+    g = install_guards(monkeypatch)
     _CURRENT.append(g)
     yield g
     _CURRENT.pop()
